@@ -1,0 +1,25 @@
+"""dla_future_amd -- MI355X-native tiled distributed Cholesky behind the DLA-Future interface.
+
+The product is the C-ABI shared library ``dla_future_amd/lib/libdlaf_mi355x.so`` (hand-written
+gfx950 HIP kernels + a thin C++ host over HIP streams/events and RCCL).  This package is the
+Python doorway onto that ABI, mirroring the reference's operator surface for the path:
+
+    dlaf_initialize / dlaf_finalize                    include/dlaf_c/init.h
+    dlaf_create_grid* / dlaf_free_grid                 include/dlaf_c/grid.h
+    dlaf_cholesky_factorization_{s,d,c,z}              include/dlaf_c/factorization/cholesky.h:32-47
+    dlaf_p{s,d,c,z}potrf                               include/dlaf_c/factorization/cholesky.h:74-87
+    dlaf::cholesky_factorization(uplo, Matrix&)        include/dlaf/factorization/cholesky.h:39-79
+
+There is no CPU fallback: importing works anywhere, every compute call needs the HIP library
+and a GPU and fails loudly otherwise.
+"""
+from .capi import (DLAFDescriptor, LibraryNotBuilt, lib, lib_path, type_char, version)  # noqa: F401
+from .cholesky import (DeviceMatrix, Grid, cholesky_factorization, finalize, initialize, make_descriptor,  # noqa: F401
+                       pxpotrf, set_random_hermitian_positive_definite, tile_gemm, tile_herk, tile_potrf,
+                       tile_trsm)
+from . import distribution  # noqa: F401
+
+__all__ = ["DLAFDescriptor", "DeviceMatrix", "Grid", "LibraryNotBuilt", "cholesky_factorization", "distribution",
+           "finalize", "initialize", "lib", "lib_path", "make_descriptor", "pxpotrf",
+           "set_random_hermitian_positive_definite", "tile_gemm", "tile_herk", "tile_potrf", "tile_trsm",
+           "type_char", "version"]

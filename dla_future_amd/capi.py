@@ -1,0 +1,112 @@
+"""ctypes binding of libdlaf_mi355x.so (include/dlaf_c/*.h + include/dlaf_mi355x/dlaf_mi355x.h)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class LibraryNotBuilt(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "lib", "libdlaf_mi355x.so")
+
+
+class DLAFDescriptor(C.Structure):
+    """struct DLAF_descriptor (include/dlaf_c/desc.h; reference desc.h:16-26)."""
+    _fields_ = [("m", C.c_int), ("n", C.c_int), ("mb", C.c_int), ("nb", C.c_int), ("isrc", C.c_int),
+                ("jsrc", C.c_int), ("i", C.c_int), ("j", C.c_int), ("ld", C.c_int)]
+
+
+BCAST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t)
+BARRIER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+_TYPE_CHARS = {np.dtype(np.float32): "s", np.dtype(np.float64): "d", np.dtype(np.complex64): "c",
+               np.dtype(np.complex128): "z"}
+
+
+def type_char(dtype) -> str:
+    try:
+        return _TYPE_CHARS[np.dtype(dtype)]
+    except KeyError:
+        raise TypeError(f"unsupported element type {dtype}: expected float32/64 or complex64/128") from None
+
+
+# every symbol the headers declare: name -> (restype, argtypes)
+_vp, _i, _l, _ch = C.c_void_p, C.c_int, C.c_long, C.c_char
+_IP = C.POINTER(C.c_int)
+SIGNATURES = {
+    # include/dlaf_c/init.h
+    "dlaf_initialize": (None, [_i, C.POINTER(C.c_char_p), _i, C.POINTER(C.c_char_p)]),
+    "dlaf_finalize": (None, []),
+    # include/dlaf_c/grid.h
+    "dlaf_free_grid": (None, [_i]),
+    # include/dlaf_c/utils.h
+    "make_dlaf_descriptor": (DLAFDescriptor, [_i, _i, _i, _i, _IP]),
+    # include/dlaf_c/factorization/cholesky.h
+    "dlaf_cholesky_factorization_s": (_i, [_i, _ch, _vp, DLAFDescriptor]),
+    "dlaf_cholesky_factorization_d": (_i, [_i, _ch, _vp, DLAFDescriptor]),
+    "dlaf_cholesky_factorization_c": (_i, [_i, _ch, _vp, DLAFDescriptor]),
+    "dlaf_cholesky_factorization_z": (_i, [_i, _ch, _vp, DLAFDescriptor]),
+    "dlaf_pspotrf": (None, [_ch, _i, _vp, _i, _i, _IP, _IP]),
+    "dlaf_pdpotrf": (None, [_ch, _i, _vp, _i, _i, _IP, _IP]),
+    "dlaf_pcpotrf": (None, [_ch, _i, _vp, _i, _i, _IP, _IP]),
+    "dlaf_pzpotrf": (None, [_ch, _i, _vp, _i, _i, _IP, _IP]),
+    # include/dlaf_mi355x/dlaf_mi355x.h
+    "dlaf_mi355x_version": (C.c_char_p, []),
+    "dlaf_mi355x_create_grid_single": (_i, []),
+    "dlaf_mi355x_rccl_unique_id": (None, [_vp]),
+    "dlaf_mi355x_create_grid_rccl": (_i, [_vp, _i, _i, _i, _i, _ch]),
+    "dlaf_mi355x_create_grid_host": (_i, [_i, _i, _i, _i, _ch, BCAST_FN, BARRIER_FN, _vp]),
+    "dlaf_mi355x_grid_info": (_i, [_i, _IP, _IP, _IP, _IP]),
+    "dlaf_mi355x_grid_barrier": (_i, [_i]),
+    "dlaf_mi355x_matrix_create": (_i, [_i, _ch, _ch, DLAFDescriptor, C.POINTER(_vp)]),
+    "dlaf_mi355x_matrix_destroy": (None, [_vp]),
+    "dlaf_mi355x_matrix_upload": (_i, [_vp, _vp, _i]),
+    "dlaf_mi355x_matrix_download": (_i, [_vp, _vp, _i]),
+    "dlaf_mi355x_matrix_copy": (_i, [_vp, _vp]),
+    "dlaf_mi355x_cholesky_start": (_i, [_vp]),
+    "dlaf_mi355x_cholesky_wait": (_i, [_vp]),
+    "dlaf_mi355x_cholesky_factorization_device": (_i, [_vp]),
+    "dlaf_mi355x_set_random_hpd": (_i, [_i, _ch, _vp, DLAFDescriptor, _i]),
+    "dlaf_mi355x_tile_potrf": (_i, [_ch, _ch, _i, _vp, _i]),
+    "dlaf_mi355x_tile_trsm": (_i, [_ch, _ch, _i, _i, _vp, _i, _vp, _i]),
+    "dlaf_mi355x_tile_herk": (_i, [_ch, _ch, _i, _i, _vp, _i, _vp, _i]),
+    "dlaf_mi355x_tile_gemm": (_i, [_ch, _ch, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i]),
+    "dlaf_mi355x_dist_owner": (_i, [_l, _i, _i]),
+    "dlaf_mi355x_dist_local_tile": (_l, [_l, _i, _i, _i]),
+    "dlaf_mi355x_dist_next_local_tile": (_l, [_l, _i, _i, _i]),
+    "dlaf_mi355x_dist_global_tile": (_l, [_l, _i, _i, _i]),
+    "dlaf_mi355x_dist_local_size": (_l, [_l, _i, _i, _i, _i]),
+    "dlaf_mi355x_dist_local_tiles": (_l, [_l, _i, _i, _i, _i]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libdlaf_mi355x.so and type every entry point.  Raises LibraryNotBuilt when the HIP
+    library is missing: there is deliberately no other implementation to fall back to."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise LibraryNotBuilt(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950); dla_future_amd has no CPU fallback")
+    L = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        f = getattr(L, name)  # AttributeError here = header/library drift, which must be loud
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+def version() -> str:
+    return lib().dlaf_mi355x_version().decode()

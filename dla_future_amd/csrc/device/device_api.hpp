@@ -1,0 +1,107 @@
+// device_api.hpp -- host-callable launchers of the gfx950 tile kernels.  Everything here
+// enqueues work on the given HIP stream and returns; no allocation, no synchronisation
+// (the launchers are hipGraph-capturable).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+
+namespace dlaf_mi355x {
+
+// Block size of the diagonal factorization / inverted diagonal blocks used by the TRSM.
+constexpr int kDiagBlock = 64;
+
+// ------------------------------------------------------------------------------------------
+// Trailing update (tile::herk + tile::gemm of a whole step in ONE launch):
+//   for local tiles (il, jl) in [il0,il1) x [jl0,jl1) with global indices gi = il*pr + ri,
+//   gj = jl*pc + ci:   gi > gj:  C(il,jl) -= A(il) * B(jl)^H          (gemm, impl.h:83-94)
+//                      gi == gj: lower(C(il,jl)) -= A(il) * B(jl)^H   (herk, impl.h:70-80)
+//                      gi < gj:  nothing
+// C lives in tile layout (tile (il,jl) at c + il*c_tsr + jl*c_tsc, leading dimension ldc);
+// A(il) = a + (il-il0)*a_ts (rows(gi) x K, lda), B(jl) = b + (jl-jl0)*b_ts (rows(gj) x K, ldb).
+// rows(g) = nb except for the last global tile g == nt-1 which has last_rows.
+template <class T>
+struct UpdateArgs {
+  T* c;
+  long c_tsr, c_tsc;
+  int ldc;
+  const T* a;
+  long a_ts;
+  int lda;
+  const T* b;
+  long b_ts;
+  int ldb;
+  int il0, il1, jl0, jl1;
+  int nb, K;
+  int pr, ri, pc, ci;
+  int nt, last_rows;
+  const int* info;  // device flag: non-zero => a previous POTRF failed, kernels return at once
+};
+template <class T>
+void launch_update(const UpdateArgs<T>& args, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------
+// Panel TRSM (tile::trsm Right/Lower/ConjTrans/NonUnit of a whole panel in ONE launch,
+// impl.h:56-67):   X(il) = B(il) * L^-H for local tiles il in [il0, il1), in place.
+// L: n x n lower triangular (ldl); winv: ceil(n/64) inverted diagonal blocks of L, block j is a
+// dense 64 x 64 column-major array at winv + j*64*64 (lower triangle valid, rest zero).
+template <class T>
+struct TrsmArgs {
+  T* b;
+  long b_ts;
+  int ldb;
+  int il0, il1;
+  int pr, ri;
+  int nb, nt, last_rows;
+  const T* l;
+  int ldl;
+  const T* winv;
+  int n;
+  const int* info;
+};
+template <class T>
+void launch_trsm(const TrsmArgs<T>& args, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------
+// Diagonal block factorization + inversion (one workgroup):  a (jb x jb, lda, jb <= 64) is
+// overwritten by its lower Cholesky factor (strict upper part untouched); winv_block (64 x 64,
+// ld 64) receives inv(L) (lower, zero elsewhere).  On a non-positive pivot at column c the
+// kernel stores info_base + c + 1 into *info (first failure wins) and leaves garbage.
+// factor == false: a already holds a lower triangular matrix; only winv_block is produced.
+template <class T>
+void launch_potrf_diag(T* a, int lda, int jb, T* winv_block, int* info, int info_base, hipStream_t stream,
+                       bool factor = true);
+
+// ------------------------------------------------------------------------------------------
+// Layout kernels between the caller's column-major local array (staged on the device) and the
+// tile layout (tile (il,jl) at dst + (il + jl*ltr) * nb*nb, ld = nb).
+//   transpose == 0: tile(il,jl)[r][c]  = src[(il*nb + r) + (jl*nb + c)*lds]     (uplo = L)
+//   transpose == 1: tile(il,jl)[r][c]  = src[(jl*nb + c) + (il*nb + r)*lds]     (uplo = U seen as
+//                   the lower factorization of the transposed view; the view's tile grid is
+//                   ltr x ltc with ltr = source tile COLUMNS)
+// Only view-tiles with global row index >= global column index are moved (the uplo triangle);
+// within diagonal tiles every element is moved to the device and only the triangle is moved back.
+template <class T>
+struct LayoutArgs {
+  T* tiles;
+  T* cm;         // column-major local array on the device
+  long ld_cm;
+  int ltr, ltc;  // local tile rows / cols of the (possibly transposed) VIEW
+  int nb;
+  long rows, cols;  // local element extents of the VIEW
+  int pr, ri, pc, ci;  // global tile index of view-tile: gi = il*pr + ri, gj = jl*pc + ci
+  int transpose;
+};
+template <class T>
+void launch_to_tiles(const LayoutArgs<T>& args, hipStream_t stream);
+template <class T>
+void launch_from_tiles(const LayoutArgs<T>& args, hipStream_t stream);
+
+template <class T>
+void launch_copy2d(T* dst, long ldd, const T* src, long lds, int rows, int cols, int transpose, int mask,
+                   hipStream_t stream);
+
+// one-off: opt the kernels into > 64 KiB of dynamic LDS
+void device_kernels_init();
+
+}  // namespace dlaf_mi355x

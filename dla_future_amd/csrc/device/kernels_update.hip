@@ -1,0 +1,204 @@
+// kernels_update.hip -- trailing-matrix update of one Cholesky step as ONE grouped launch.
+//
+// Reference: cholesky/impl.h:70-94 (herkTrailingDiagTile / gemmTrailingMatrixTile), issued one
+// tile at a time by the loops at impl.h:168-187 (local) and :273-300 (distributed) through
+// rocBLAS (blas/tile.h:370-382, :414-425).  Here the whole set of local trailing tiles is one
+// kernel: each workgroup owns a BM x BN block of one tile, accumulates A(il)*B(jl)^H over K with
+// fp64/fp32 MFMA register tiles fed from LDS-staged panel slabs, and applies C -= acc once.
+//   * blockIdx -> block mapping is XCD-aware: the 8 XCDs get contiguous runs of 8x8-block
+//     patches so that the panel slabs a patch shares stay in that XCD's L2;
+//   * herk is the same code with a lower-triangle mask on diagonal tiles (and a real diagonal
+//     for complex types).
+// Roofline: MFMA-bound, 2*nb^3 flop per 4*nb^2*sizeof(T) algorithmic bytes per tile.
+#include "device_api.hpp"
+#include "mma_core.hpp"
+
+namespace dlaf_mi355x {
+
+template <class T>
+struct UpdateCfg;
+template <>
+struct UpdateCfg<float> {
+  using type = BlockCfg<float, 128, 128, 64, 64, 16>;
+  static constexpr int min_waves = 2;
+};
+template <>
+struct UpdateCfg<double> {
+  using type = BlockCfg<double, 128, 128, 64, 64, 16>;
+  static constexpr int min_waves = 2;
+};
+template <>
+struct UpdateCfg<cfloat> {
+  using type = BlockCfg<cfloat, 128, 128, 64, 64, 16>;
+  static constexpr int min_waves = 2;
+};
+template <>
+struct UpdateCfg<cdouble> {
+  using type = BlockCfg<cdouble, 128, 64, 64, 32, 8>;
+  static constexpr int min_waves = 2;
+};
+
+struct UpdateMap {
+  int ps;        // patch = (1<<ps) x (1<<ps) blocks
+  int PR;        // patch rows
+  int tri;       // triangular patch enumeration (square local domain, lower part only)
+  int xcd;       // remap blockIdx so each XCD works on consecutive patches
+  int RB, CB;    // block rows / cols of the domain
+  int bpt_m, bpt_n;
+};
+
+template <class T, bool VEC>
+__global__ __launch_bounds__(kThreads, UpdateCfg<T>::min_waves) void update_kernel(UpdateArgs<T> p, UpdateMap mp) {
+  using Cfg = typename UpdateCfg<T>::type;
+  using R = real_t<T>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  R* lds = reinterpret_cast<R*>(lds_raw);
+
+  if (*p.info != 0)
+    return;
+
+  // ---- which block am I ------------------------------------------------------------------
+  const unsigned b = blockIdx.x;
+  const long w = mp.xcd ? (long) (b & 7u) * (gridDim.x >> 3) + (b >> 3) : (long) b;
+  const int ps = mp.ps;
+  const long patch = w >> (2 * ps);
+  const int q = (int) (w & ((1 << (2 * ps)) - 1));
+  int pi, pj;
+  if (mp.tri) {
+    pi = (int) ((sqrt(8.0 * (double) patch + 1.0) - 1.0) * 0.5);
+    while ((long) pi * (pi + 1) / 2 > patch)
+      --pi;
+    while ((long) (pi + 1) * (pi + 2) / 2 <= patch)
+      ++pi;
+    pj = (int) (patch - (long) pi * (pi + 1) / 2);
+  }
+  else {
+    pi = (int) (patch % mp.PR);
+    pj = (int) (patch / mp.PR);
+  }
+  const int br = (pi << ps) + (q & ((1 << ps) - 1));
+  const int bc = (pj << ps) + (q >> ps);
+  if (br >= mp.RB || bc >= mp.CB)
+    return;
+  const int il = p.il0 + br / mp.bpt_m, sbr = br % mp.bpt_m;
+  const int jl = p.jl0 + bc / mp.bpt_n, sbc = bc % mp.bpt_n;
+  const int gi = il * p.pr + p.ri, gj = jl * p.pc + p.ci;
+  if (gi < gj)
+    return;
+  const int rows_tile = (gi == p.nt - 1) ? p.last_rows : p.nb;
+  const int cols_tile = (gj == p.nt - 1) ? p.last_rows : p.nb;
+  const int m0 = sbr * Cfg::BM, n0 = sbc * Cfg::BN;
+  if (m0 >= rows_tile || n0 >= cols_tile)
+    return;
+  const bool diag = (gi == gj);
+  const int mrows = min(Cfg::BM, rows_tile - m0), ncols = min(Cfg::BN, cols_tile - n0);
+  if (diag && m0 + mrows - 1 < n0)
+    return;  // block strictly above the diagonal of a diagonal tile
+
+  const T* A = p.a + (long) (il - p.il0) * p.a_ts + m0;
+  // herk on a diagonal tile reads the COLUMN panel for both operands (impl.h:282-287): the
+  // transposed panel never holds the tile of the last global row (broadcast_panel.h:186-191)
+  const T* B = diag ? p.a + (long) (il - p.il0) * p.a_ts + n0 : p.b + (long) (jl - p.jl0) * p.b_ts + n0;
+  const long ldb = diag ? p.lda : p.ldb;
+  T* C = p.c + (long) il * p.c_tsr + (long) jl * p.c_tsc + m0 + (long) n0 * p.ldc;
+
+  const bool full = (mrows == Cfg::BM) && (ncols == Cfg::BN) && (p.K % Cfg::BK == 0);
+  Acc<Cfg> acc;
+  acc.clear();
+  if (full)
+    gemm_nt_block<Cfg, T, VEC, false>(A, p.lda, mrows, B, ldb, ncols, p.K, lds, acc);
+  else
+    gemm_nt_block<Cfg, T, false, true>(A, p.lda, mrows, B, ldb, ncols, p.K, lds, acc);
+
+  // ---- epilogue: C -= acc -------------------------------------------------------------------
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave % Cfg::WAVES_M, wn = wave / Cfg::WAVES_M;
+  const int g = lane >> 4, c = lane & 15;
+  const bool masked = !full || (diag && m0 < n0 + ncols - 1);
+#pragma unroll
+  for (int j = 0; j < Cfg::TN; ++j) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int nl = wn * Cfg::WN + j * 16 + Mma<R>::irow(g, v);
+      T* col = C + (long) nl * p.ldc;
+      T cv[Cfg::TM];
+      bool ok[Cfg::TM];
+#pragma unroll
+      for (int i = 0; i < Cfg::TM; ++i) {
+        const int ml = wm * Cfg::WM + i * 16 + c;
+        ok[i] = !masked || (ml < mrows && nl < ncols && (!diag || (m0 + ml) >= (n0 + nl)));
+        if (ok[i])
+          cv[i] = col[ml];
+      }
+#pragma unroll
+      for (int i = 0; i < Cfg::TM; ++i) {
+        const int ml = wm * Cfg::WM + i * 16 + c;
+        if (ok[i]) {
+          if constexpr (Cfg::CX) {
+            T r{cv[i].re - acc.re[i][j][v], cv[i].im - acc.im[i][j][v]};
+            if (diag && (m0 + ml) == (n0 + nl))
+              r.im = R(0);
+            col[ml] = r;
+          }
+          else {
+            col[ml] = cv[i] - acc.re[i][j][v];
+          }
+        }
+      }
+    }
+  }
+}
+
+template <class T>
+static bool aligned16(const void* ptr, long stride_elems) {
+  return (reinterpret_cast<uintptr_t>(ptr) % 16 == 0) && ((stride_elems * (long) sizeof(T)) % 16 == 0);
+}
+
+template <class T>
+void launch_update(const UpdateArgs<T>& a, hipStream_t stream) {
+  using Cfg = typename UpdateCfg<T>::type;
+  if (a.il1 <= a.il0 || a.jl1 <= a.jl0 || a.K <= 0 || a.nb <= 0)
+    return;
+  UpdateMap mp;
+  mp.bpt_m = (a.nb + Cfg::BM - 1) / Cfg::BM;
+  mp.bpt_n = (a.nb + Cfg::BN - 1) / Cfg::BN;
+  mp.RB = (a.il1 - a.il0) * mp.bpt_m;
+  mp.CB = (a.jl1 - a.jl0) * mp.bpt_n;
+  mp.tri = (Cfg::BM == Cfg::BN && a.pr == 1 && a.pc == 1 && a.ri == a.ci && a.il0 == a.jl0 && a.il1 == a.jl1) ? 1 : 0;
+  mp.ps = (mp.RB >= 16 && mp.CB >= 16) ? 3 : 0;
+  const int psz = 1 << mp.ps;
+  mp.PR = (mp.RB + psz - 1) / psz;
+  const int PC = (mp.CB + psz - 1) / psz;
+  const long npatch = mp.tri ? (long) mp.PR * (mp.PR + 1) / 2 : (long) mp.PR * PC;
+  const long grid = npatch << (2 * mp.ps);
+  mp.xcd = (mp.ps > 0) ? 1 : 0;
+  const bool vec = aligned16<T>(a.a, a.lda) && aligned16<T>(a.a, a.a_ts) && aligned16<T>(a.b, a.ldb) &&
+                   aligned16<T>(a.b, a.b_ts);
+  if (vec)
+    hipLaunchKernelGGL((update_kernel<T, true>), dim3((unsigned) grid), dim3(kThreads), Cfg::LDS_BYTES, stream, a, mp);
+  else
+    hipLaunchKernelGGL((update_kernel<T, false>), dim3((unsigned) grid), dim3(kThreads), Cfg::LDS_BYTES, stream, a, mp);
+}
+
+template <class T>
+static void update_init_one() {
+  using Cfg = typename UpdateCfg<T>::type;
+  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&update_kernel<T, true>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&update_kernel<T, false>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+}
+
+void update_kernels_init() {
+  update_init_one<float>();
+  update_init_one<double>();
+  update_init_one<cfloat>();
+  update_init_one<cdouble>();
+}
+
+template void launch_update<float>(const UpdateArgs<float>&, hipStream_t);
+template void launch_update<double>(const UpdateArgs<double>&, hipStream_t);
+template void launch_update<cfloat>(const UpdateArgs<cfloat>&, hipStream_t);
+template void launch_update<cdouble>(const UpdateArgs<cdouble>&, hipStream_t);
+
+}  // namespace dlaf_mi355x

@@ -1,0 +1,403 @@
+// c_api.cpp -- the extern "C" surface: the reference's dlaf_c entry points for the Cholesky path
+// (include/dlaf_c/{init,grid,utils}.h, include/dlaf_c/factorization/cholesky.h; implemented upstream
+// in src/c_api/{init,grid,utils}.cpp and src/c_api/factorization/cholesky.{h,cpp}) plus the
+// MI355X extensions declared in include/dlaf_mi355x/dlaf_mi355x.h.
+#include <climits>
+#include <complex>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <unordered_map>
+
+#include <dlaf_c/factorization/cholesky.h>
+#include <dlaf_c/grid.h>
+#include <dlaf_c/init.h>
+#include <dlaf_mi355x/dlaf_mi355x.h>
+
+#include "runtime.hpp"
+
+using namespace dlaf_mi355x;
+
+namespace dlaf_mi355x {
+template <class T>
+void set_random_hpd_local(T* a, long ld, long n, int nb, const Axis& rows, const Axis& cols, int nthreads);
+}
+
+namespace {
+// grid registry: contexts count down from INT_MAX (reference: src/c_api/grid.cpp:26-31)
+std::unordered_map<int, std::unique_ptr<Grid>> g_grids;
+
+int register_grid(std::unique_ptr<Grid> g) {
+  const int ctx = INT_MAX - (int) g_grids.size();
+  g_grids[ctx] = std::move(g);
+  return ctx;
+}
+
+Grid& grid_from_context(int ctx) {
+  auto it = g_grids.find(ctx);
+  if (it == g_grids.end())
+    // reference: src/c_api/utils.cpp:55-68 prints this and terminates
+    fatal("[ERROR] No DLA-Future grid for context %d. Did you forget to call dlaf_create_grid()?\n", ctx);
+  return *it->second;
+}
+
+bool coords_from_rank(int rank, int nprow, int npcol, char order, int& myrow, int& mycol) {
+  if (order == 'C' || order == 'c') {  // reference: common/index2d.h:345-355
+    myrow = rank % nprow;
+    mycol = rank / nprow;
+  }
+  else {
+    myrow = rank / npcol;
+    mycol = rank % npcol;
+  }
+  return myrow < nprow && mycol < npcol;
+}
+
+std::unique_ptr<Grid> make_grid(int nranks, int rank, int nprow, int npcol, char order) {
+  if (nprow < 1 || npcol < 1 || nprow * npcol != nranks || rank < 0 || rank >= nranks)
+    return nullptr;
+  auto g = std::make_unique<Grid>();
+  g->nprow = nprow;
+  g->npcol = npcol;
+  g->rank = rank;
+  g->nranks = nranks;
+  g->order = (order == 'C' || order == 'c') ? 'C' : 'R';
+  coords_from_rank(rank, nprow, npcol, g->order, g->myrow, g->mycol);
+  return g;
+}
+
+template <class T>
+struct DevType;
+template <>
+struct DevType<float> {
+  using type = float;
+};
+template <>
+struct DevType<double> {
+  using type = double;
+};
+template <>
+struct DevType<std::complex<float>> {
+  using type = cfloat;
+};
+template <>
+struct DevType<std::complex<double>> {
+  using type = cdouble;
+};
+
+void check_cholesky_desc(const DLAF_descriptor& d) {
+  // preconditions of dlaf::cholesky_factorization (include/dlaf/factorization/cholesky.h:39-79) and of
+  // the C wrapper (src/c_api/factorization/cholesky.h:37-38); upstream asserts -> terminate
+  if (d.i != 0 || d.j != 0)
+    fatal("[dlaf_mi355x] sub-matrices are not supported: i = %d, j = %d must be 0\n", d.i, d.j);
+  if (d.m != d.n)
+    fatal("[dlaf_mi355x] Cholesky needs a square matrix: %d x %d\n", d.m, d.n);
+  if (d.mb != d.nb || d.nb < 1)
+    fatal("[dlaf_mi355x] Cholesky needs square blocks: %d x %d\n", d.mb, d.nb);
+  if (d.m < 0)
+    fatal("[dlaf_mi355x] negative matrix size %d\n", d.m);
+}
+
+template <class HT>
+int cholesky_host(int ctx, char uplo, HT* a, const DLAF_descriptor& d) {
+  using DT = typename DevType<HT>::type;
+  check_cholesky_desc(d);
+  if (!(uplo == 'L' || uplo == 'l' || uplo == 'U' || uplo == 'u'))
+    fatal("[dlaf_mi355x] uplo must be 'L' or 'U', got '%c'\n", uplo);
+  Grid& g = grid_from_context(ctx);
+  if (d.isrc < 0 || d.isrc >= g.nprow || d.jsrc < 0 || d.jsrc >= g.npcol)
+    fatal("[dlaf_mi355x] source rank (%d,%d) outside the %d x %d grid\n", d.isrc, d.jsrc, g.nprow, g.npcol);
+  DeviceMatrix<DT> m;
+  m.create(&g, uplo, d.m, d.nb, d.isrc, d.jsrc);
+  m.upload(reinterpret_cast<const DT*>(a), d.ld);
+  const int info = m.factorize();
+  if (info == 0)
+    m.download(reinterpret_cast<DT*>(a), d.ld);
+  return info;
+}
+
+template <class HT>
+void pxpotrf(char uplo, int n, HT* a, int ia, int ja, const int desca[9], int* info) {
+  // reference: src/c_api/factorization/cholesky.h:65-75
+  if (desca[0] != 1)
+    fatal("[dlaf_mi355x] desca[0] (dtype) must be 1, got %d\n", desca[0]);
+  if (ia != 1 || ja != 1)
+    fatal("[dlaf_mi355x] ia = %d, ja = %d must be 1\n", ia, ja);
+  const DLAF_descriptor d = make_dlaf_descriptor(n, n, ia, ja, desca);
+  const int r = cholesky_host<HT>(desca[1], uplo, a, d);
+  if (info)
+    *info = r;
+}
+
+struct MatrixHandle {
+  std::unique_ptr<MatrixBase> m;
+  char type;
+  int ctx;
+};
+
+template <class F>
+int dispatch_type(char type, F&& f) {
+  switch (type) {
+    case 's': return f((float*) nullptr);
+    case 'd': return f((double*) nullptr);
+    case 'c': return f((cfloat*) nullptr);
+    case 'z': return f((cdouble*) nullptr);
+    default: return -2;
+  }
+}
+}  // namespace
+
+struct dlaf_mi355x_matrix_s : MatrixHandle {};
+
+// =================================================================================== dlaf_c
+extern "C" {
+
+void dlaf_initialize(int, const char**, int argc_dlaf, const char** argv_dlaf) noexcept {
+  const bool first = !runtime_initialized();
+  runtime_init();
+  for (int i = 0; first && argv_dlaf && i < argc_dlaf; ++i)
+    if (argv_dlaf[i] && std::strcmp(argv_dlaf[i], "--dlaf:print-config") == 0) {
+      int dev = -1;
+      (void) hipGetDevice(&dev);
+      hipDeviceProp_t p;
+      (void) hipGetDeviceProperties(&p, dev);
+      std::printf("DLA-Future MI355X build: device %d (%s, %d CUs), diag block %d\n", dev, p.gcnArchName,
+                  p.multiProcessorCount, kDiagBlock);
+    }
+}
+
+void dlaf_finalize(void) noexcept {
+  g_grids.clear();
+  runtime_finalize();
+}
+
+void dlaf_free_grid(int context) noexcept {
+  g_grids.erase(context);
+}
+
+DLAF_descriptor make_dlaf_descriptor(const int m, const int n, const int i, const int j, const int desc[9]) noexcept {
+  if (i != 1 || j != 1)
+    fatal("[dlaf_mi355x] make_dlaf_descriptor: i = %d, j = %d must be 1\n", i, j);
+  DLAF_descriptor d = {m, n, desc[4], desc[5], desc[6], desc[7], i - 1, j - 1, desc[8]};
+  return d;
+}
+
+int dlaf_cholesky_factorization_s(const int ctx, const char uplo, float* a, const DLAF_descriptor d) noexcept {
+  return cholesky_host<float>(ctx, uplo, a, d);
+}
+int dlaf_cholesky_factorization_d(const int ctx, const char uplo, double* a, const DLAF_descriptor d) noexcept {
+  return cholesky_host<double>(ctx, uplo, a, d);
+}
+int dlaf_cholesky_factorization_c(const int ctx, const char uplo, dlaf_complex_c* a, const DLAF_descriptor d) noexcept {
+  return cholesky_host<std::complex<float>>(ctx, uplo, a, d);
+}
+int dlaf_cholesky_factorization_z(const int ctx, const char uplo, dlaf_complex_z* a, const DLAF_descriptor d) noexcept {
+  return cholesky_host<std::complex<double>>(ctx, uplo, a, d);
+}
+
+void dlaf_pspotrf(const char uplo, const int n, float* a, const int ia, const int ja, const int desca[9],
+                  int* info) noexcept {
+  pxpotrf<float>(uplo, n, a, ia, ja, desca, info);
+}
+void dlaf_pdpotrf(const char uplo, const int n, double* a, const int ia, const int ja, const int desca[9],
+                  int* info) noexcept {
+  pxpotrf<double>(uplo, n, a, ia, ja, desca, info);
+}
+void dlaf_pcpotrf(const char uplo, const int n, dlaf_complex_c* a, const int ia, const int ja, const int desca[9],
+                  int* info) noexcept {
+  pxpotrf<std::complex<float>>(uplo, n, a, ia, ja, desca, info);
+}
+void dlaf_pzpotrf(const char uplo, const int n, dlaf_complex_z* a, const int ia, const int ja, const int desca[9],
+                  int* info) noexcept {
+  pxpotrf<std::complex<double>>(uplo, n, a, ia, ja, desca, info);
+}
+
+// =================================================================================== extensions
+const char* dlaf_mi355x_version(void) noexcept {
+  return "dlaf_mi355x 0.1 gfx950";
+}
+
+int dlaf_mi355x_create_grid_single(void) noexcept {
+  return register_grid(make_grid(1, 0, 1, 1, 'R'));
+}
+
+void dlaf_mi355x_rccl_unique_id(void* out) noexcept {
+  runtime_init();
+  rccl_get_unique_id(out);
+}
+
+int dlaf_mi355x_create_grid_rccl(const void* uid, int nranks, int rank, int nprow, int npcol, char order) noexcept {
+  auto g = make_grid(nranks, rank, nprow, npcol, order);
+  if (!g)
+    return -1;
+  runtime_init();
+  if (nranks > 1)
+    g->transport = make_rccl_transport(uid, nranks, rank, nprow, npcol, g->myrow, g->mycol);
+  return register_grid(std::move(g));
+}
+
+int dlaf_mi355x_create_grid_host(int nranks, int rank, int nprow, int npcol, char order, dlaf_mi355x_bcast_fn bcast,
+                                 dlaf_mi355x_barrier_fn barrier, void* user) noexcept {
+  auto g = make_grid(nranks, rank, nprow, npcol, order);
+  if (!g || (nranks > 1 && !bcast))
+    return -1;
+  if (nranks > 1)
+    g->transport = make_host_transport(bcast, barrier, user);
+  return register_grid(std::move(g));
+}
+
+int dlaf_mi355x_grid_info(int ctx, int* nprow, int* npcol, int* myrow, int* mycol) noexcept {
+  auto it = g_grids.find(ctx);
+  if (it == g_grids.end())
+    return -1;
+  const Grid& g = *it->second;
+  if (nprow) *nprow = g.nprow;
+  if (npcol) *npcol = g.npcol;
+  if (myrow) *myrow = g.myrow;
+  if (mycol) *mycol = g.mycol;
+  return 0;
+}
+
+int dlaf_mi355x_grid_barrier(int ctx) noexcept {
+  auto it = g_grids.find(ctx);
+  if (it == g_grids.end())
+    return -1;
+  if (it->second->transport)
+    it->second->transport->barrier(nullptr);
+  else
+    (void) hipDeviceSynchronize();
+  return 0;
+}
+
+int dlaf_mi355x_matrix_create(int ctx, char type, char uplo, DLAF_descriptor d, dlaf_mi355x_matrix_t* out) noexcept {
+  if (!out)
+    return -1;
+  auto it = g_grids.find(ctx);
+  if (it == g_grids.end())
+    return -1;
+  Grid* g = it->second.get();
+  if (d.i != 0 || d.j != 0 || d.m != d.n || d.mb != d.nb || d.nb < 1 || d.m < 0)
+    return -3;
+  if (d.isrc < 0 || d.isrc >= g->nprow || d.jsrc < 0 || d.jsrc >= g->npcol)
+    return -3;
+  if (!(uplo == 'L' || uplo == 'l' || uplo == 'U' || uplo == 'u'))
+    return -4;
+  auto* h = new dlaf_mi355x_matrix_s;
+  h->type = type;
+  h->ctx = ctx;
+  const int r = dispatch_type(type, [&](auto* tag) {
+    using DT = std::remove_pointer_t<decltype(tag)>;
+    auto m = std::make_unique<DeviceMatrix<DT>>();
+    m->create(g, uplo, d.m, d.nb, d.isrc, d.jsrc);
+    h->m = std::move(m);
+    return 0;
+  });
+  if (r != 0) {
+    delete h;
+    return r;
+  }
+  *out = h;
+  return 0;
+}
+
+void dlaf_mi355x_matrix_destroy(dlaf_mi355x_matrix_t m) noexcept {
+  delete m;
+}
+
+#define WITH_MATRIX(handle, body)                                       \
+  if (!(handle) || !(handle)->m)                                        \
+    return -1;                                                          \
+  return dispatch_type((handle)->type, [&](auto* tag) -> int {         \
+    using DT = std::remove_pointer_t<decltype(tag)>;                    \
+    auto& M = static_cast<DeviceMatrix<DT>&>(*(handle)->m);             \
+    body                                                                \
+  });
+
+int dlaf_mi355x_matrix_upload(dlaf_mi355x_matrix_t h, const void* host, int ld) noexcept {
+  WITH_MATRIX(h, M.upload(static_cast<const DT*>(host), ld); return 0;)
+}
+int dlaf_mi355x_matrix_download(dlaf_mi355x_matrix_t h, void* host, int ld) noexcept {
+  WITH_MATRIX(h, M.download(static_cast<DT*>(host), ld); return 0;)
+}
+int dlaf_mi355x_matrix_copy(dlaf_mi355x_matrix_t dst, dlaf_mi355x_matrix_t src) noexcept {
+  if (!src || !dst || src->type != dst->type)
+    return -1;
+  WITH_MATRIX(dst, M.copy_from(static_cast<DeviceMatrix<DT>&>(*src->m)); return 0;)
+}
+int dlaf_mi355x_cholesky_start(dlaf_mi355x_matrix_t h) noexcept {
+  WITH_MATRIX(h, M.factorize_async(); return 0;)
+}
+int dlaf_mi355x_cholesky_wait(dlaf_mi355x_matrix_t h) noexcept {
+  WITH_MATRIX(h, return M.wait();)
+}
+int dlaf_mi355x_cholesky_factorization_device(dlaf_mi355x_matrix_t h) noexcept {
+  WITH_MATRIX(h, return M.factorize();)
+}
+
+int dlaf_mi355x_set_random_hpd(int ctx, char type, void* host, DLAF_descriptor d, int nthreads) noexcept {
+  auto it = g_grids.find(ctx);
+  if (it == g_grids.end())
+    return -1;
+  const Grid& g = *it->second;
+  if (d.m != d.n || d.mb != d.nb || d.nb < 1)
+    return -3;
+  Axis rows{d.m, d.nb, g.nprow, g.myrow, d.isrc}, cols{d.n, d.nb, g.npcol, g.mycol, d.jsrc};
+  switch (type) {
+    case 's': set_random_hpd_local(static_cast<float*>(host), d.ld, d.m, d.nb, rows, cols, nthreads); break;
+    case 'd': set_random_hpd_local(static_cast<double*>(host), d.ld, d.m, d.nb, rows, cols, nthreads); break;
+    case 'c': set_random_hpd_local(static_cast<std::complex<float>*>(host), d.ld, d.m, d.nb, rows, cols, nthreads); break;
+    case 'z': set_random_hpd_local(static_cast<std::complex<double>*>(host), d.ld, d.m, d.nb, rows, cols, nthreads); break;
+    default: return -2;
+  }
+  return 0;
+}
+
+int dlaf_mi355x_tile_potrf(char type, char uplo, int n, void* a, int lda) noexcept {
+  return dispatch_type(type, [&](auto* tag) {
+    using DT = std::remove_pointer_t<decltype(tag)>;
+    return tile_potrf<DT>(uplo, n, static_cast<DT*>(a), lda);
+  });
+}
+int dlaf_mi355x_tile_trsm(char type, char uplo, int m, int n, const void* a, int lda, void* b, int ldb) noexcept {
+  return dispatch_type(type, [&](auto* tag) {
+    using DT = std::remove_pointer_t<decltype(tag)>;
+    tile_trsm<DT>(uplo, m, n, static_cast<const DT*>(a), lda, static_cast<DT*>(b), ldb);
+    return 0;
+  });
+}
+int dlaf_mi355x_tile_herk(char type, char uplo, int n, int k, const void* a, int lda, void* c, int ldc) noexcept {
+  return dispatch_type(type, [&](auto* tag) {
+    using DT = std::remove_pointer_t<decltype(tag)>;
+    tile_herk<DT>(uplo, n, k, static_cast<const DT*>(a), lda, static_cast<DT*>(c), ldc);
+    return 0;
+  });
+}
+int dlaf_mi355x_tile_gemm(char type, char uplo, int m, int n, int k, const void* a, int lda, const void* b, int ldb,
+                          void* c, int ldc) noexcept {
+  return dispatch_type(type, [&](auto* tag) {
+    using DT = std::remove_pointer_t<decltype(tag)>;
+    tile_gemm<DT>(uplo, m, n, k, static_cast<const DT*>(a), lda, static_cast<const DT*>(b), ldb, static_cast<DT*>(c), ldc);
+    return 0;
+  });
+}
+
+int dlaf_mi355x_dist_owner(long gt, int gs, int src) noexcept {
+  return Axis{0, 1, gs, 0, src}.owner(gt);
+}
+long dlaf_mi355x_dist_local_tile(long gt, int gs, int rank, int src) noexcept {
+  return Axis{0, 1, gs, rank, src}.local_of(gt);
+}
+long dlaf_mi355x_dist_next_local_tile(long gt, int gs, int rank, int src) noexcept {
+  return Axis{0, 1, gs, rank, src}.next_local(gt);
+}
+long dlaf_mi355x_dist_global_tile(long lt, int gs, int rank, int src) noexcept {
+  return Axis{0, 1, gs, rank, src}.global_of(lt);
+}
+long dlaf_mi355x_dist_local_size(long n, int nb, int gs, int rank, int src) noexcept {
+  return Axis{n, nb, gs, rank, src}.local_size();
+}
+long dlaf_mi355x_dist_local_tiles(long n, int nb, int gs, int rank, int src) noexcept {
+  return Axis{n, nb, gs, rank, src}.local_tiles();
+}
+
+}  // extern "C"

@@ -1,0 +1,748 @@
+// runtime.cpp -- device matrix, stream/event executor of the right-looking tile DAG, tile ops.
+// See runtime.hpp for what each piece replaces in the reference.
+#include "runtime.hpp"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <exception>
+
+namespace dlaf_mi355x {
+
+void fatal(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  std::vfprintf(stderr, fmt, ap);
+  va_end(ap);
+  std::fflush(stderr);
+  std::terminate();  // same failure mode as DLAF_ASSERT (include/dlaf/common/assert.h:58-77)
+}
+
+static bool g_initialized = false;
+
+void runtime_init() {
+  if (g_initialized)
+    return;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    fatal("[dlaf_mi355x] no HIP device available: this library has no CPU fallback\n");
+  // one process per GPU: honour LOCAL_RANK the way torch.distributed launchers export it
+  int dev = 0;
+  if (const char* lr = std::getenv("LOCAL_RANK"))
+    dev = std::atoi(lr) % ndev;
+  if (const char* d = std::getenv("DLAF_MI355X_DEVICE"))
+    dev = std::atoi(d) % ndev;
+  DLAF_HIP_CHECK(hipSetDevice(dev));
+  device_kernels_init();
+  g_initialized = true;
+}
+
+void runtime_finalize() {
+  if (!g_initialized)
+    return;
+  (void) hipDeviceSynchronize();
+  g_initialized = false;
+}
+
+bool runtime_initialized() {
+  return g_initialized;
+}
+
+// =============================================================================== host transport
+namespace {
+class HostTransport final : public Transport {
+public:
+  HostTransport(dlaf_host_bcast_fn b, dlaf_host_barrier_fn bar, void* user) : bcast_(b), barrier_(bar), user_(user) {}
+  ~HostTransport() override {
+    if (pinned_)
+      (void) hipHostFree(pinned_);
+  }
+  bool device_side() const override { return false; }
+  void bcast(CommAxis axis, int root, int my_index, const void* send, void* recv, size_t bytes,
+             hipStream_t stream) override {
+    if (bytes == 0)
+      return;
+    reserve(bytes);
+    DLAF_HIP_CHECK(hipStreamSynchronize(stream));
+    if (my_index == root)
+      DLAF_HIP_CHECK(hipMemcpy(pinned_, send, bytes, hipMemcpyDeviceToHost));
+    if (bcast_(user_, (int) axis, root, pinned_, bytes) != 0)
+      fatal("[dlaf_mi355x] host broadcast callback failed\n");
+    DLAF_HIP_CHECK(hipMemcpyAsync(recv, pinned_, bytes, hipMemcpyHostToDevice, stream));
+    DLAF_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  void barrier(hipStream_t stream) override {
+    DLAF_HIP_CHECK(hipStreamSynchronize(stream));
+    if (barrier_ && barrier_(user_) != 0)
+      fatal("[dlaf_mi355x] host barrier callback failed\n");
+  }
+
+private:
+  void reserve(size_t bytes) {
+    if (bytes <= cap_)
+      return;
+    if (pinned_)
+      DLAF_HIP_CHECK(hipHostFree(pinned_));
+    DLAF_HIP_CHECK(hipHostMalloc(&pinned_, bytes, hipHostMallocDefault));
+    cap_ = bytes;
+  }
+  dlaf_host_bcast_fn bcast_;
+  dlaf_host_barrier_fn barrier_;
+  void* user_;
+  void* pinned_ = nullptr;
+  size_t cap_ = 0;
+};
+}  // namespace
+
+std::unique_ptr<Transport> make_host_transport(dlaf_host_bcast_fn b, dlaf_host_barrier_fn bar, void* user) {
+  return std::unique_ptr<Transport>(new HostTransport(b, bar, user));
+}
+
+// =============================================================================== DeviceMatrix
+template <class T>
+static T* dev_alloc(size_t elems) {
+  T* p = nullptr;
+  if (elems == 0)
+    elems = 1;
+  DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), elems * sizeof(T)));
+  return p;
+}
+
+static std::vector<hipEvent_t> make_events(size_t n) {
+  std::vector<hipEvent_t> v(n);
+  for (auto& e : v)
+    DLAF_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return v;
+}
+
+template <class T>
+void DeviceMatrix<T>::create(Grid* g, char uplo_, long n_, int nb_, int isrc, int jsrc) {
+  runtime_init();
+  type = TypeInfo<T>::tag;
+  grid = g;
+  uplo = (uplo_ == 'U' || uplo_ == 'u') ? 'U' : 'L';
+  transposed = (uplo == 'U');
+  n = n_;
+  nb = nb_;
+  Axis srow{n, nb, g->nprow, g->myrow, isrc};
+  Axis scol{n, nb, g->npcol, g->mycol, jsrc};
+  rows = transposed ? scol : srow;
+  cols = transposed ? srow : scol;
+  nt = rows.nt();
+  ltr = rows.local_tiles();
+  ltc = cols.local_tiles();
+  tile_elems = (size_t) nb * nb;
+
+  tiles = dev_alloc<T>((size_t) ltr * ltc * tile_elems);
+  winv = dev_alloc<T>(winv_elems());
+  const bool dist = g->nranks > 1;
+  if (dist) {
+    diag_ws = dev_alloc<T>(tile_elems + winv_elems());
+    for (int b = 0; b < 2; ++b) {
+      panel[b] = dev_alloc<T>((size_t) ltr * tile_elems);
+      panelT[b] = dev_alloc<T>((size_t) ltc * tile_elems);
+    }
+  }
+  DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&info), sizeof(int)));
+  DLAF_HIP_CHECK(hipMemset(info, 0, sizeof(int)));
+  DLAF_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&info_host), sizeof(int), hipHostMallocDefault));
+  *info_host = 0;
+
+  // POTRF / TRSM / lookahead column on a high-priority stream, the bulk of the trailing update on a
+  // normal one (the reference's priority rule, cholesky/impl.h:172-173, src/init.cpp:70-83)
+  int lo = 0, hi = 0;
+  DLAF_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  DLAF_HIP_CHECK(hipStreamCreateWithPriority(&s_high, hipStreamNonBlocking, hi));
+  DLAF_HIP_CHECK(hipStreamCreateWithPriority(&s_low, hipStreamNonBlocking, lo));
+  DLAF_HIP_CHECK(hipStreamCreateWithPriority(&s_comm, hipStreamNonBlocking, hi));
+  const size_t ne = (size_t) (nt > 0 ? nt : 1);
+  ev_panel = make_events(ne);
+  ev_low = make_events(ne);
+  ev_high = make_events(ne);
+  ev_diag = make_events(ne);
+  ev_bcast = make_events(ne);
+  ev_bcastT = make_events(2);
+}
+
+template <class T>
+void DeviceMatrix<T>::destroy() {
+  if (!tiles)
+    return;
+  (void) hipDeviceSynchronize();
+  for (auto* v : {&ev_panel, &ev_low, &ev_high, &ev_diag, &ev_bcast, &ev_bcastT}) {
+    for (auto e : *v)
+      (void) hipEventDestroy(e);
+    v->clear();
+  }
+  (void) hipStreamDestroy(s_high);
+  (void) hipStreamDestroy(s_low);
+  (void) hipStreamDestroy(s_comm);
+  (void) hipFree(tiles);
+  (void) hipFree(winv);
+  if (diag_ws)
+    (void) hipFree(diag_ws);
+  for (int b = 0; b < 2; ++b) {
+    if (panel[b])
+      (void) hipFree(panel[b]);
+    if (panelT[b])
+      (void) hipFree(panelT[b]);
+  }
+  if (staging)
+    (void) hipFree(staging);
+  (void) hipFree(info);
+  (void) hipHostFree(info_host);
+  tiles = nullptr;
+}
+
+template <class T>
+static LayoutArgs<T> layout_args(const DeviceMatrix<T>& m, T* cm, long ld_cm) {
+  LayoutArgs<T> a;
+  a.tiles = m.tiles;
+  a.cm = cm;
+  a.ld_cm = ld_cm;
+  a.ltr = (int) m.ltr;
+  a.ltc = (int) m.ltc;
+  a.nb = m.nb;
+  a.rows = m.rows.local_size();
+  a.cols = m.cols.local_size();
+  a.pr = m.rows.P;
+  a.ri = m.rows.shift();
+  a.pc = m.cols.P;
+  a.ci = m.cols.shift();
+  a.transpose = m.transposed ? 1 : 0;
+  return a;
+}
+
+// Source (caller-side) local extents: rows/cols of the UNtransposed distribution.
+template <class T>
+static void source_extents(const DeviceMatrix<T>& m, long& srows, long& scols) {
+  srows = m.transposed ? m.cols.local_size() : m.rows.local_size();
+  scols = m.transposed ? m.rows.local_size() : m.cols.local_size();
+}
+
+template <class T>
+static void ensure_staging(DeviceMatrix<T>& m, size_t elems) {
+  if (m.staging && m.staging_elems >= elems)
+    return;
+  if (m.staging)
+    DLAF_HIP_CHECK(hipFree(m.staging));
+  m.staging = dev_alloc<T>(elems);
+  m.staging_elems = elems;
+}
+
+template <class T>
+void DeviceMatrix<T>::upload(const T* host, long ld) {
+  long srows, scols;
+  source_extents(*this, srows, scols);
+  if (srows == 0 || scols == 0)
+    return;
+  const long lds = srows;
+  ensure_staging(*this, (size_t) lds * scols);
+  DLAF_HIP_CHECK(hipMemcpy2DAsync(staging, (size_t) lds * sizeof(T), host, (size_t) ld * sizeof(T),
+                                  (size_t) srows * sizeof(T), (size_t) scols, hipMemcpyHostToDevice, s_high));
+  launch_to_tiles(layout_args(*this, staging, lds), s_high);
+  DLAF_HIP_CHECK(hipStreamSynchronize(s_high));
+}
+
+template <class T>
+void DeviceMatrix<T>::download(T* host, long ld) {
+  long srows, scols;
+  source_extents(*this, srows, scols);
+  if (srows == 0 || scols == 0)
+    return;
+  const long lds = srows;
+  ensure_staging(*this, (size_t) lds * scols);
+  // the untouched triangle must come back unchanged: stage the caller's current content first
+  DLAF_HIP_CHECK(hipMemcpy2DAsync(staging, (size_t) lds * sizeof(T), host, (size_t) ld * sizeof(T),
+                                  (size_t) srows * sizeof(T), (size_t) scols, hipMemcpyHostToDevice, s_high));
+  launch_from_tiles(layout_args(*this, staging, lds), s_high);
+  DLAF_HIP_CHECK(hipMemcpy2DAsync(host, (size_t) ld * sizeof(T), staging, (size_t) lds * sizeof(T),
+                                  (size_t) srows * sizeof(T), (size_t) scols, hipMemcpyDeviceToHost, s_high));
+  DLAF_HIP_CHECK(hipStreamSynchronize(s_high));
+}
+
+template <class T>
+void DeviceMatrix<T>::copy_from(const DeviceMatrix<T>& o) {
+  if (o.n != n || o.nb != nb || o.ltr != ltr || o.ltc != ltc || o.transposed != transposed)
+    fatal("[dlaf_mi355x] copy_from: matrices differ in shape or distribution\n");
+  DLAF_HIP_CHECK(hipMemcpyAsync(tiles, o.tiles, (size_t) ltr * ltc * tile_elems * sizeof(T),
+                                hipMemcpyDeviceToDevice, s_high));
+  DLAF_HIP_CHECK(hipStreamSynchronize(s_high));
+}
+
+// ------------------------------------------------------------------------------- tile POTRF
+// Blocked lower Cholesky of one kb x kb tile (ld) with inner block 64: diagonal block kernel,
+// sub-panel solve (TRSM kernel, one column block), in-tile trailing update (update kernel).
+// winv receives the ceil(kb/64) inverted diagonal blocks.  Replaces rocsolver potrf
+// (lapack/tile.h:577-606).
+template <class T>
+static void potrf_tile(T* t, int ld, int kb, T* winv, int* info, int info_base, hipStream_t s) {
+  constexpr int JB = kDiagBlock;
+  for (int j0 = 0; j0 < kb; j0 += JB) {
+    const int jb = std::min(JB, kb - j0);
+    T* djj = t + j0 + (size_t) j0 * ld;
+    T* wj = winv + (size_t) (j0 / JB) * JB * JB;
+    launch_potrf_diag(djj, ld, jb, wj, info, info_base + j0, s);
+    const int rem = kb - j0 - jb;
+    if (rem <= 0)
+      break;
+    T* sub = t + (j0 + jb) + (size_t) j0 * ld;  // rem x jb panel below the diagonal block
+    TrsmArgs<T> ta;
+    ta.b = sub;
+    ta.b_ts = 0;
+    ta.ldb = ld;
+    ta.il0 = 0;
+    ta.il1 = 1;
+    ta.pr = 1;
+    ta.ri = 0;
+    ta.nb = rem;
+    ta.nt = 1;
+    ta.last_rows = rem;
+    ta.l = djj;
+    ta.ldl = ld;
+    ta.winv = wj;
+    ta.n = jb;
+    ta.info = info;
+    launch_trsm(ta, s);
+    UpdateArgs<T> ua;
+    ua.c = t + (j0 + jb) + (size_t) (j0 + jb) * ld;
+    ua.c_tsr = ua.c_tsc = 0;
+    ua.ldc = ld;
+    ua.a = sub;
+    ua.a_ts = 0;
+    ua.lda = ld;
+    ua.b = sub;
+    ua.b_ts = 0;
+    ua.ldb = ld;
+    ua.il0 = ua.jl0 = 0;
+    ua.il1 = ua.jl1 = 1;
+    ua.nb = rem;
+    ua.K = jb;
+    ua.pr = ua.pc = 1;
+    ua.ri = ua.ci = 0;
+    ua.nt = 1;
+    ua.last_rows = rem;
+    ua.info = info;
+    launch_update(ua, s);
+  }
+}
+
+// ------------------------------------------------------------------------------- the tile DAG
+// Right-looking Cholesky (cholesky/impl.h:150-189 local, :192-313 distributed) of the lower
+// triangle of the view.  Per step k:
+//   s_high : POTRF(k,k) -> [diag tile bcast down the owning process column] -> panel TRSM
+//            -> update of tile column k+1 (the reference's high-priority lookahead column)
+//   s_comm : panel bcast along process rows, transposed-panel bcast along process columns
+//   s_low  : update of tile columns > k+1
+// Events carry the RAW/WAR edges the reference gets from per-tile async_rw_mutex.
+template <class T>
+void DeviceMatrix<T>::factorize_async() {
+  Transport* tr = grid->transport.get();
+  const bool dist = grid->nranks > 1;
+  if (dist && !tr)
+    fatal("[dlaf_mi355x] grid with %d ranks has no transport\n", grid->nranks);
+  const size_t tile_bytes = tile_elems * sizeof(T);
+  const int last_rows = rows.last_extent();
+  // uplo == 'U' runs on the transposed view: its process rows are the caller's process columns
+  const CommAxis ax_row = transposed ? CommAxis::Col : CommAxis::Row;
+  const CommAxis ax_col = transposed ? CommAxis::Row : CommAxis::Col;
+
+  DLAF_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int), s_high));
+  DLAF_HIP_CHECK(hipEventRecord(ev_bcastT[0], s_high));
+  DLAF_HIP_CHECK(hipStreamWaitEvent(s_low, ev_bcastT[0], 0));
+  DLAF_HIP_CHECK(hipStreamWaitEvent(s_comm, ev_bcastT[0], 0));
+
+  auto update = [&](const T* a_base, long a_il0, const T* b_base, long b_ts, long b_jl0, long j0, long j1,
+                    int kb, hipStream_t s) {
+    if (j0 >= j1)
+      return;
+    // rows that can hold tiles on/below the diagonal of column block j0
+    const long il0 = std::max(a_il0, rows.next_local(cols.global_of(j0)));
+    if (il0 >= ltr)
+      return;
+    UpdateArgs<T> ua;
+    ua.c = tiles;
+    ua.c_tsr = (long) tile_elems;
+    ua.c_tsc = (long) (tile_elems * ltr);
+    ua.ldc = nb;
+    ua.a = a_base + (size_t) (il0 - a_il0) * tile_elems;
+    ua.a_ts = (long) tile_elems;
+    ua.lda = nb;
+    ua.b = b_base + (j0 - b_jl0) * b_ts;
+    ua.b_ts = b_ts;
+    ua.ldb = nb;
+    ua.il0 = (int) il0;
+    ua.il1 = (int) ltr;
+    ua.jl0 = (int) j0;
+    ua.jl1 = (int) j1;
+    ua.nb = nb;
+    ua.K = kb;
+    ua.pr = rows.P;
+    ua.ri = rows.shift();
+    ua.pc = cols.P;
+    ua.ci = cols.shift();
+    ua.nt = (int) nt;
+    ua.last_rows = last_rows;
+    ua.info = info;
+    launch_update(ua, s);
+  };
+
+  for (long k = 0; k < nt; ++k) {
+    const int kb = rows.tile_extent(k);
+    const int own_r = rows.owner(k), own_c = cols.owner(k);
+    const bool in_row = rows.rank == own_r, in_col = cols.rank == own_c;
+    const long il_n = rows.next_local(k + 1), jl_n = cols.next_local(k + 1);
+    const int buf = (int) (k & 1);
+    const long klc = in_col ? cols.local_of(k) : -1;
+
+    // ---- diagonal tile ---------------------------------------------------------------------------
+    const T* Lkk = nullptr;
+    const T* Wkk = nullptr;
+    if (in_row && in_col) {
+      T* tkk = tile(rows.local_of(k), klc);
+      potrf_tile(tkk, nb, kb, winv, info, (int) (k * nb), s_high);
+      Lkk = tkk;
+      Wkk = winv;
+    }
+    if (k == nt - 1)
+      break;
+
+    // ---- diag tile down the owning process column, then the panel TRSM -------------------------
+    if (in_col) {
+      if (rows.P > 1) {
+        if (in_row) {
+          DLAF_HIP_CHECK(hipMemcpyAsync(diag_ws, Lkk, tile_bytes, hipMemcpyDeviceToDevice, s_high));
+          DLAF_HIP_CHECK(hipMemcpyAsync(diag_ws + tile_elems, Wkk, winv_elems() * sizeof(T),
+                                        hipMemcpyDeviceToDevice, s_high));
+        }
+        // s_high is past the previous step's TRSM (last reader of diag_ws) at this point
+        DLAF_HIP_CHECK(hipEventRecord(ev_diag[k], s_high));
+        DLAF_HIP_CHECK(hipStreamWaitEvent(s_comm, ev_diag[k], 0));
+        tr->bcast(ax_col, own_r, rows.rank, diag_ws, diag_ws, tile_bytes + winv_elems() * sizeof(T), s_comm);
+        DLAF_HIP_CHECK(hipEventRecord(ev_diag[k], s_comm));
+        DLAF_HIP_CHECK(hipStreamWaitEvent(s_high, ev_diag[k], 0));
+        Lkk = diag_ws;
+        Wkk = diag_ws + tile_elems;
+      }
+      if (il_n < ltr) {
+        TrsmArgs<T> ta;
+        ta.b = tile(il_n, klc);
+        ta.b_ts = (long) tile_elems;
+        ta.ldb = nb;
+        ta.il0 = (int) il_n;
+        ta.il1 = (int) ltr;
+        ta.pr = rows.P;
+        ta.ri = rows.shift();
+        ta.nb = nb;
+        ta.nt = (int) nt;
+        ta.last_rows = last_rows;
+        ta.l = Lkk;
+        ta.ldl = nb;
+        ta.winv = Wkk;
+        ta.n = kb;
+        ta.info = info;
+        launch_trsm(ta, s_high);
+      }
+    }
+    DLAF_HIP_CHECK(hipEventRecord(ev_panel[k], s_high));
+
+    // ---- panel along process rows, transposed panel along process columns ---------------------
+    const T* a_base = nullptr;  // column panel: tile of local row il at a_base + (il - il_n)*tile_elems
+    const T* b_base = nullptr;  // transposed panel: tile of local col jl at b_base + (jl - jl_n)*b_ts
+    long b_ts = (long) tile_elems;
+    bool comm_used = false;
+    if (dist) {
+      DLAF_HIP_CHECK(hipStreamWaitEvent(s_comm, ev_panel[k], 0));
+      if (k >= 2) {  // the workspaces of step k-2 are about to be overwritten
+        DLAF_HIP_CHECK(hipStreamWaitEvent(s_comm, ev_low[k - 2], 0));
+        DLAF_HIP_CHECK(hipStreamWaitEvent(s_comm, ev_high[k - 2], 0));
+      }
+    }
+    if (cols.P > 1) {
+      T* dst = in_col ? tile(il_n < ltr ? il_n : 0, klc) : panel[buf];
+      if (il_n < ltr) {
+        tr->bcast(ax_row, own_c, cols.rank, dst, dst, (size_t) (ltr - il_n) * tile_bytes, s_comm);
+        comm_used = true;
+      }
+      a_base = dst;
+    }
+    else {
+      a_base = tile(il_n < ltr ? il_n : 0, klc);
+    }
+    if (rows.P > 1) {
+      tr->group_begin();
+      for (long jl = jl_n; jl < ltc; ++jl) {
+        const long gj = cols.global_of(jl);
+        if (gj == nt - 1)
+          continue;  // last tile row is only ever a herk operand (broadcast_panel.h:186-191)
+        const int root_r = rows.owner(gj);
+        const T* src = (rows.rank == root_r) ? a_base + (size_t) (rows.local_of(gj) - il_n) * tile_elems : nullptr;
+        tr->bcast(ax_col, root_r, rows.rank, src, panelT[buf] + (size_t) (jl - jl_n) * tile_elems, tile_bytes,
+                  s_comm);
+        comm_used = true;
+      }
+      tr->group_end();
+      b_base = panelT[buf];
+    }
+    else {
+      // I hold every row of the panel: tile gj sits at local row gj
+      b_base = a_base + (cols.global_of(jl_n) - il_n) * (long) tile_elems;
+      b_ts = (long) tile_elems * cols.P;
+    }
+    if (dist) {
+      DLAF_HIP_CHECK(hipEventRecord(ev_bcast[k], s_comm));
+      DLAF_HIP_CHECK(hipStreamWaitEvent(s_high, ev_bcast[k], 0));
+      DLAF_HIP_CHECK(hipStreamWaitEvent(s_low, ev_bcast[k], 0));
+    }
+    (void) comm_used;
+
+    // ---- trailing update: lookahead column on s_high, the rest on s_low --------------------------
+    if (k >= 1)
+      DLAF_HIP_CHECK(hipStreamWaitEvent(s_high, ev_low[k - 1], 0));
+    long rest0 = jl_n;
+    if (cols.mine(k + 1) && jl_n < ltc) {
+      update(a_base, il_n, b_base, b_ts, jl_n, jl_n, jl_n + 1, kb, s_high);
+      rest0 = jl_n + 1;
+    }
+    DLAF_HIP_CHECK(hipEventRecord(ev_high[k], s_high));
+    DLAF_HIP_CHECK(hipStreamWaitEvent(s_low, ev_panel[k], 0));
+    update(a_base, il_n, b_base, b_ts, jl_n, rest0, ltc, kb, s_low);
+    DLAF_HIP_CHECK(hipEventRecord(ev_low[k], s_low));
+  }
+  DLAF_HIP_CHECK(hipMemcpyAsync(info_host, info, sizeof(int), hipMemcpyDeviceToHost, s_high));
+}
+
+template <class T>
+int DeviceMatrix<T>::wait() {
+  DLAF_HIP_CHECK(hipStreamSynchronize(s_comm));
+  DLAF_HIP_CHECK(hipStreamSynchronize(s_low));
+  DLAF_HIP_CHECK(hipStreamSynchronize(s_high));
+  DLAF_HIP_CHECK(hipMemcpy(info_host, info, sizeof(int), hipMemcpyDeviceToHost));
+  return *info_host;
+}
+
+template <class T>
+int DeviceMatrix<T>::factorize() {
+  factorize_async();
+  return wait();
+}
+
+// =============================================================================== single-tile ops
+namespace {
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  explicit DevBuf(size_t elems) { p = dev_alloc<T>(elems); }
+  ~DevBuf() { (void) hipFree(p); }
+};
+
+// host (rows x cols, ld) -> dense device buffer in "device orientation" (transposed when tr)
+template <class T>
+void to_device(T* dst, const T* host, int ld, int rows, int cols, bool tr, T* tmp, hipStream_t s) {
+  if (rows == 0 || cols == 0)
+    return;
+  T* raw = tr ? tmp : dst;
+  DLAF_HIP_CHECK(hipMemcpy2DAsync(raw, (size_t) rows * sizeof(T), host, (size_t) ld * sizeof(T),
+                                  (size_t) rows * sizeof(T), (size_t) cols, hipMemcpyHostToDevice, s));
+  if (tr)
+    launch_copy2d(dst, (long) cols, raw, (long) rows, cols, rows, 1, 0, s);
+}
+}  // namespace
+
+template <class T>
+int tile_potrf(char uplo, int n, T* a, int lda) {
+  runtime_init();
+  if (n == 0)
+    return 0;
+  const bool tr = (uplo == 'U' || uplo == 'u');
+  hipStream_t s = nullptr;
+  DevBuf<T> da((size_t) n * n), tmp((size_t) n * n), w((size_t) ((n + kDiagBlock - 1) / kDiagBlock) * kDiagBlock * kDiagBlock);
+  DevBuf<int> info(1);
+  DLAF_HIP_CHECK(hipMemsetAsync(info.p, 0, sizeof(int), s));
+  // tmp keeps the caller's image (host orientation); da the device orientation
+  DLAF_HIP_CHECK(hipMemcpy2DAsync(tmp.p, (size_t) n * sizeof(T), a, (size_t) lda * sizeof(T), (size_t) n * sizeof(T),
+                                  (size_t) n, hipMemcpyHostToDevice, s));
+  launch_copy2d(da.p, (long) n, tmp.p, (long) n, n, n, tr ? 1 : 0, 0, s);
+  potrf_tile(da.p, n, n, w.p, info.p, 0, s);
+  launch_copy2d(tmp.p, (long) n, da.p, (long) n, n, n, tr ? 1 : 0, tr ? 2 : 1, s);
+  DLAF_HIP_CHECK(hipMemcpy2DAsync(a, (size_t) lda * sizeof(T), tmp.p, (size_t) n * sizeof(T), (size_t) n * sizeof(T),
+                                  (size_t) n, hipMemcpyDeviceToHost, s));
+  int h = 0;
+  DLAF_HIP_CHECK(hipMemcpyAsync(&h, info.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  DLAF_HIP_CHECK(hipStreamSynchronize(s));
+  return h;
+}
+
+// uplo L: B(m x n) <- B A^-H, A n x n lower.   uplo U: B(m x n) <- A^-H B, A m x m upper.
+// (the two variants the factorization issues: cholesky/impl.h:56-67 and :110-121)
+template <class T>
+void tile_trsm(char uplo, int m, int n, const T* a, int lda, T* b, int ldb) {
+  runtime_init();
+  if (m == 0 || n == 0)
+    return;
+  const bool tr = (uplo == 'U' || uplo == 'u');
+  const int na = tr ? m : n;             // order of the triangular matrix
+  const int br = tr ? n : m, bc = na;    // device-orientation extents of B
+  hipStream_t s = nullptr;
+  const size_t wel = (size_t) ((na + kDiagBlock - 1) / kDiagBlock) * kDiagBlock * kDiagBlock;
+  DevBuf<T> da((size_t) na * na), tmpa((size_t) na * na), db((size_t) m * n), tmpb((size_t) m * n), w(wel);
+  DevBuf<int> info(1);
+  DLAF_HIP_CHECK(hipMemsetAsync(info.p, 0, sizeof(int), s));
+  to_device(da.p, a, lda, na, na, tr, tmpa.p, s);
+  to_device(db.p, b, ldb, m, n, tr, tmpb.p, s);
+  // inverted diagonal blocks of the (already triangular) factor: invert-only mode of the diag kernel
+  for (int j0 = 0; j0 < na; j0 += kDiagBlock) {
+    const int jb = std::min(kDiagBlock, na - j0);
+    launch_potrf_diag(da.p + j0 + (size_t) j0 * na, na, jb, w.p + (size_t) (j0 / kDiagBlock) * kDiagBlock * kDiagBlock,
+                      info.p, 0, s, false);
+  }
+  TrsmArgs<T> ta;
+  ta.b = db.p;
+  ta.b_ts = 0;
+  ta.ldb = br;
+  ta.il0 = 0;
+  ta.il1 = 1;
+  ta.pr = 1;
+  ta.ri = 0;
+  ta.nb = br;
+  ta.nt = 1;
+  ta.last_rows = br;
+  ta.l = da.p;
+  ta.ldl = na;
+  ta.winv = w.p;
+  ta.n = bc;
+  ta.info = info.p;
+  launch_trsm(ta, s);
+  T* out = tr ? tmpb.p : db.p;
+  if (tr)
+    launch_copy2d(tmpb.p, (long) m, db.p, (long) br, m, n, 1, 0, s);
+  DLAF_HIP_CHECK(hipMemcpy2DAsync(b, (size_t) ldb * sizeof(T), out, (size_t) m * sizeof(T), (size_t) m * sizeof(T),
+                                  (size_t) n, hipMemcpyDeviceToHost, s));
+  DLAF_HIP_CHECK(hipStreamSynchronize(s));
+}
+
+// uplo L: lower(C) -= A A^H, A n x k.   uplo U: upper(C) -= A^H A, A k x n.   (impl.h:70-80, :124-134)
+template <class T>
+void tile_herk(char uplo, int n, int k, const T* a, int lda, T* c, int ldc) {
+  runtime_init();
+  if (n == 0)
+    return;
+  const bool tr = (uplo == 'U' || uplo == 'u');
+  hipStream_t s = nullptr;
+  const int ar = tr ? k : n, ac = tr ? n : k;  // host extents of A
+  DevBuf<T> da((size_t) n * std::max(k, 1)), tmpa((size_t) n * std::max(k, 1)), dc((size_t) n * n), tmpc((size_t) n * n);
+  DevBuf<int> info(1);
+  DLAF_HIP_CHECK(hipMemsetAsync(info.p, 0, sizeof(int), s));
+  to_device(da.p, a, lda, ar, ac, tr, tmpa.p, s);
+  DLAF_HIP_CHECK(hipMemcpy2DAsync(tmpc.p, (size_t) n * sizeof(T), c, (size_t) ldc * sizeof(T), (size_t) n * sizeof(T),
+                                  (size_t) n, hipMemcpyHostToDevice, s));
+  launch_copy2d(dc.p, (long) n, tmpc.p, (long) n, n, n, tr ? 1 : 0, 0, s);
+  UpdateArgs<T> ua;
+  ua.c = dc.p;
+  ua.c_tsr = ua.c_tsc = 0;
+  ua.ldc = n;
+  ua.a = da.p;
+  ua.a_ts = 0;
+  ua.lda = n;
+  ua.b = da.p;
+  ua.b_ts = 0;
+  ua.ldb = n;
+  ua.il0 = ua.jl0 = 0;
+  ua.il1 = ua.jl1 = 1;
+  ua.nb = n;
+  ua.K = k;
+  ua.pr = ua.pc = 1;
+  ua.ri = ua.ci = 0;
+  ua.nt = 1;
+  ua.last_rows = n;
+  ua.info = info.p;
+  launch_update(ua, s);
+  launch_copy2d(tmpc.p, (long) n, dc.p, (long) n, n, n, tr ? 1 : 0, tr ? 2 : 1, s);
+  DLAF_HIP_CHECK(hipMemcpy2DAsync(c, (size_t) ldc * sizeof(T), tmpc.p, (size_t) n * sizeof(T), (size_t) n * sizeof(T),
+                                  (size_t) n, hipMemcpyDeviceToHost, s));
+  DLAF_HIP_CHECK(hipStreamSynchronize(s));
+}
+
+// uplo L: C(m x n) -= A B^H, A m x k, B n x k.   uplo U: C -= A^H B, A k x m, B k x n.
+// (impl.h:83-94, :137-147)
+template <class T>
+void tile_gemm(char uplo, int m, int n, int k, const T* a, int lda, const T* b, int ldb, T* c, int ldc) {
+  runtime_init();
+  if (m == 0 || n == 0)
+    return;
+  const bool tr = (uplo == 'U' || uplo == 'u');
+  hipStream_t s = nullptr;
+  // device orientation: C' = C (L) or C^T (U), extents cm x cn; row operand A' (cm x k), column
+  // operand B' (cn x k).  For U:  C^T -= B^T conj(A) = B' A'^H with B' = B^T as ROW operand.
+  const int cm = tr ? n : m, cn = tr ? m : n;
+  const int kk = std::max(k, 1);
+  // the update kernel works on square tiles: pad the single tile to sq x sq with zero rows
+  const int sq = std::max(cm, cn);
+  DevBuf<T> dA((size_t) cm * kk), dB((size_t) cn * kk), tmp((size_t) std::max(m, n) * kk), tmpc((size_t) m * n);
+  DevBuf<T> pA((size_t) sq * kk), pB((size_t) sq * kk), pC((size_t) sq * sq);
+  DevBuf<int> info(1);
+  DLAF_HIP_CHECK(hipMemsetAsync(info.p, 0, sizeof(int), s));
+  DLAF_HIP_CHECK(hipMemsetAsync(pA.p, 0, (size_t) sq * kk * sizeof(T), s));
+  DLAF_HIP_CHECK(hipMemsetAsync(pB.p, 0, (size_t) sq * kk * sizeof(T), s));
+  DLAF_HIP_CHECK(hipMemsetAsync(pC.p, 0, (size_t) sq * sq * sizeof(T), s));
+  if (k > 0) {
+    if (!tr) {
+      to_device(dA.p, a, lda, m, k, false, tmp.p, s);
+      to_device(dB.p, b, ldb, n, k, false, tmp.p, s);
+    }
+    else {
+      to_device(dA.p, b, ldb, k, n, true, tmp.p, s);
+      DLAF_HIP_CHECK(hipStreamSynchronize(s));  // tmp is reused
+      to_device(dB.p, a, lda, k, m, true, tmp.p, s);
+    }
+    launch_copy2d(pA.p, (long) sq, dA.p, (long) cm, cm, k, 0, 0, s);
+    launch_copy2d(pB.p, (long) sq, dB.p, (long) cn, cn, k, 0, 0, s);
+  }
+  DLAF_HIP_CHECK(hipMemcpy2DAsync(tmpc.p, (size_t) m * sizeof(T), c, (size_t) ldc * sizeof(T), (size_t) m * sizeof(T),
+                                  (size_t) n, hipMemcpyHostToDevice, s));
+  launch_copy2d(pC.p, (long) sq, tmpc.p, (long) m, cm, cn, tr ? 1 : 0, 0, s);
+  // a tile strictly below the diagonal (global index (1,0) of a 3 x 3 tile grid): plain gemm
+  UpdateArgs<T> ua;
+  ua.c = pC.p;
+  ua.c_tsr = ua.c_tsc = 0;
+  ua.ldc = sq;
+  ua.a = pA.p;
+  ua.a_ts = 0;
+  ua.lda = sq;
+  ua.b = pB.p;
+  ua.b_ts = 0;
+  ua.ldb = sq;
+  ua.il0 = 1;
+  ua.il1 = 2;
+  ua.jl0 = 0;
+  ua.jl1 = 1;
+  ua.nb = sq;
+  ua.K = k;
+  ua.pr = ua.pc = 1;
+  ua.ri = ua.ci = 0;
+  ua.nt = 3;
+  ua.last_rows = sq;
+  ua.info = info.p;
+  // c_tsr = 0: tile row index does not move the base
+  launch_update(ua, s);
+  launch_copy2d(tmpc.p, (long) m, pC.p, (long) sq, m, n, tr ? 1 : 0, 0, s);
+  DLAF_HIP_CHECK(hipMemcpy2DAsync(c, (size_t) ldc * sizeof(T), tmpc.p, (size_t) m * sizeof(T), (size_t) m * sizeof(T),
+                                  (size_t) n, hipMemcpyDeviceToHost, s));
+  DLAF_HIP_CHECK(hipStreamSynchronize(s));
+}
+
+#define INST(T)                                                                                     \
+  template struct DeviceMatrix<T>;                                                                  \
+  template int tile_potrf<T>(char, int, T*, int);                                                   \
+  template void tile_trsm<T>(char, int, int, const T*, int, T*, int);                               \
+  template void tile_herk<T>(char, int, int, const T*, int, T*, int);                               \
+  template void tile_gemm<T>(char, int, int, int, const T*, int, const T*, int, T*, int);
+INST(float)
+INST(double)
+INST(cfloat)
+INST(cdouble)
+#undef INST
+
+}  // namespace dlaf_mi355x

@@ -1,0 +1,130 @@
+// runtime.hpp -- the thin C++ host of the MI355X Cholesky: grid + transport, device tile-layout
+// matrix, and the executor that issues the right-looking tile DAG onto HIP streams/events.
+//
+// It stands where the reference has pika senders + async_rw_mutex tile pipelines
+// (sender/transform.h:55-103, matrix/internal/tile_pipeline.h:36-51), the MPI communicator grid
+// (communication/communicator_grid.h:37-153) and Panel workspaces (matrix/panel.h:42-631).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <vector>
+
+#include "../device/device_api.hpp"
+#include "distribution.hpp"
+
+namespace dlaf_mi355x {
+
+[[noreturn]] void fatal(const char* fmt, ...);
+
+#define DLAF_HIP_CHECK(expr)                                                                     \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess)                                                                        \
+      ::dlaf_mi355x::fatal("[dlaf_mi355x] HIP error %s at %s:%d: %s\n", hipGetErrorName(e_), __FILE__, \
+                           __LINE__, #expr);                                                     \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// Transport: the broadcast primitive along a process row / column (communication/kernels/
+// internal/broadcast.h:36-119 in the reference: MPI_Ibcast).  Two implementations:
+//   * RCCL over xGMI: ncclBroadcast on device buffers, stream-ordered (the production path);
+//   * host callbacks: device -> pinned host -> user callback -> device.  This is the analogue of
+//     the reference's non-GPU-aware-MPI staging (sender/with_temporary_tile.h:87-204) and what the
+//     gloo-based tests and single-GPU multi-process runs use.
+enum class CommAxis : int { Row = 0, Col = 1 };
+
+// root is the rank INSIDE the row/column communicator (= process column / row index)
+typedef int (*dlaf_host_bcast_fn)(void* user, int axis, int root, void* host_buf, size_t bytes);
+typedef int (*dlaf_host_barrier_fn)(void* user);
+
+class Transport {
+public:
+  virtual ~Transport() = default;
+  virtual bool device_side() const = 0;
+  // device-side transports: enqueue on stream.  host-side: stream is synchronised first.
+  virtual void bcast(CommAxis axis, int root, int my_index, const void* send, void* recv, size_t bytes,
+                     hipStream_t stream) = 0;
+  virtual void group_begin() {}
+  virtual void group_end() {}
+  virtual void barrier(hipStream_t stream) = 0;
+};
+
+struct Grid {
+  int nprow = 1, npcol = 1;
+  int myrow = 0, mycol = 0;
+  int rank = 0, nranks = 1;
+  char order = 'R';
+  std::unique_ptr<Transport> transport;  // null for a 1x1 grid
+};
+
+std::unique_ptr<Transport> make_rccl_transport(const void* unique_id, int nranks, int rank, int nprow,
+                                               int npcol, int myrow, int mycol);
+void rccl_get_unique_id(void* out128);
+std::unique_ptr<Transport> make_host_transport(dlaf_host_bcast_fn bcast, dlaf_host_barrier_fn barrier,
+                                               void* user);
+
+// ------------------------------------------------------------------------------------------------
+// Device matrix in tile layout + the per-factorization workspaces.
+struct MatrixBase {
+  virtual ~MatrixBase() = default;
+  char type = 'd';
+};
+
+template <class T>
+struct DeviceMatrix : MatrixBase {
+  Grid* grid = nullptr;
+  char uplo = 'L';
+  bool transposed = false;  // uplo == 'U': the device holds the transposed view, factored as lower
+  Axis rows, cols;          // distribution of the VIEW
+  long n = 0;
+  int nb = 1;
+  long nt = 0;
+  long ltr = 0, ltc = 0;    // local tiles of the view
+  size_t tile_elems = 0;    // nb*nb
+
+  T* tiles = nullptr;       // ltr*ltc tiles
+  T* diag_ws = nullptr;     // nb*nb + ceil(nb/64)*64*64: received diagonal tile + its inverse blocks
+  T* winv = nullptr;        // ceil(nb/64) * 64*64 inverted diagonal blocks (owner side)
+  T* panel[2] = {nullptr, nullptr};   // ltr tiles each (received column panel)
+  T* panelT[2] = {nullptr, nullptr};  // ltc tiles each (transposed panel)
+  T* staging = nullptr;     // column-major staging for upload/download
+  size_t staging_elems = 0;
+  int* info = nullptr;      // device flag
+  int* info_host = nullptr; // pinned
+
+  hipStream_t s_high = nullptr, s_low = nullptr, s_comm = nullptr;
+  std::vector<hipEvent_t> ev_panel, ev_low, ev_high, ev_diag, ev_bcast, ev_bcastT;
+
+  T* tile(long il, long jl) const { return tiles + (size_t) (il + jl * ltr) * tile_elems; }
+  size_t winv_elems() const { return (size_t) ((nb + kDiagBlock - 1) / kDiagBlock) * kDiagBlock * kDiagBlock; }
+
+  void create(Grid* g, char uplo_, long n_, int nb_, int isrc, int jsrc);
+  void destroy();
+  ~DeviceMatrix() override { destroy(); }
+
+  void upload(const T* host, long ld);     // caller's local column-major array -> tiles
+  void download(T* host, long ld);         // tiles -> caller's array (uplo triangle only)
+  void copy_from(const DeviceMatrix<T>& other);
+  int factorize();                         // blocking; returns LAPACK-style info
+  void factorize_async();                  // enqueue only
+  int wait();                              // drain + info
+};
+
+// single-tile operations with host operands (tests of the tile kernels through the C ABI)
+template <class T>
+int tile_potrf(char uplo, int n, T* a, int lda);
+template <class T>
+void tile_trsm(char uplo, int m, int n, const T* a, int lda, T* b, int ldb);
+template <class T>
+void tile_herk(char uplo, int n, int k, const T* a, int lda, T* c, int ldc);
+template <class T>
+void tile_gemm(char uplo, int m, int n, int k, const T* a, int lda, const T* b, int ldb, T* c, int ldc);
+
+void runtime_init();
+void runtime_finalize();
+bool runtime_initialized();
+
+}  // namespace dlaf_mi355x

@@ -1,0 +1,79 @@
+// transport_rccl.cpp -- RCCL (xGMI) transport: one world communicator plus a row and a column
+// sub-communicator per process, broadcasts enqueued on the executor's communication stream.
+//
+// Replaces CommunicatorGrid's three MPI_Comm_split communicators and the MPI_Ibcast kernels
+// (src/communication/communicator_grid.cpp:20-68, communication/kernels/internal/broadcast.h:36-119).
+// Stream order on s_comm plays the role of the reference's CommunicatorPipeline token
+// (communication/communicator_pipeline.h:41-148): every member of a communicator enqueues its
+// collectives in the same program order.
+#include <rccl/rccl.h>
+
+#include <cstring>
+
+#include "runtime.hpp"
+
+namespace dlaf_mi355x {
+
+#define DLAF_NCCL_CHECK(expr)                                                                          \
+  do {                                                                                                 \
+    ncclResult_t r_ = (expr);                                                                          \
+    if (r_ != ncclSuccess)                                                                             \
+      ::dlaf_mi355x::fatal("[dlaf_mi355x] RCCL error %s at %s:%d: %s\n", ncclGetErrorString(r_), __FILE__, \
+                           __LINE__, #expr);                                                           \
+  } while (0)
+
+namespace {
+class RcclTransport final : public Transport {
+public:
+  RcclTransport(const void* unique_id, int nranks, int rank, int myrow, int mycol) {
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof(id));
+    DLAF_NCCL_CHECK(ncclCommInitRank(&world_, nranks, id, rank));
+    // row communicator: same process row, ranked by process column (and vice versa)
+    DLAF_NCCL_CHECK(ncclCommSplit(world_, myrow, mycol, &row_, nullptr));
+    DLAF_NCCL_CHECK(ncclCommSplit(world_, mycol, myrow, &col_, nullptr));
+    DLAF_HIP_CHECK(hipMalloc(&token_, sizeof(int)));
+    DLAF_HIP_CHECK(hipMemset(token_, 0, sizeof(int)));
+  }
+  ~RcclTransport() override {
+    (void) hipFree(token_);
+    if (row_)
+      (void) ncclCommDestroy(row_);
+    if (col_)
+      (void) ncclCommDestroy(col_);
+    if (world_)
+      (void) ncclCommDestroy(world_);
+  }
+  bool device_side() const override { return true; }
+  void bcast(CommAxis axis, int root, int /*my_index*/, const void* send, void* recv, size_t bytes,
+             hipStream_t stream) override {
+    if (bytes == 0)
+      return;
+    ncclComm_t c = (axis == CommAxis::Row) ? row_ : col_;
+    DLAF_NCCL_CHECK(ncclBroadcast(send ? send : recv, recv, bytes, ncclChar, root, c, stream));
+  }
+  void group_begin() override { DLAF_NCCL_CHECK(ncclGroupStart()); }
+  void group_end() override { DLAF_NCCL_CHECK(ncclGroupEnd()); }
+  void barrier(hipStream_t stream) override {
+    DLAF_NCCL_CHECK(ncclAllReduce(token_, token_, 1, ncclInt, ncclSum, world_, stream));
+    DLAF_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+
+private:
+  ncclComm_t world_ = nullptr, row_ = nullptr, col_ = nullptr;
+  void* token_ = nullptr;
+};
+}  // namespace
+
+std::unique_ptr<Transport> make_rccl_transport(const void* unique_id, int nranks, int rank, int /*nprow*/,
+                                               int /*npcol*/, int myrow, int mycol) {
+  return std::unique_ptr<Transport>(new RcclTransport(unique_id, nranks, rank, myrow, mycol));
+}
+
+void rccl_get_unique_id(void* out128) {
+  ncclUniqueId id;
+  DLAF_NCCL_CHECK(ncclGetUniqueId(&id));
+  std::memcpy(out128, &id, sizeof(id));
+}
+
+}  // namespace dlaf_mi355x

@@ -1,0 +1,21 @@
+/* dlaf_c/grid.h -- process grids.
+ * Mirrors the reference's include/dlaf_c/grid.h:31-71 (src/c_api/grid.cpp:26-92).  Contexts are
+ * handed out downwards from INT_MAX exactly like upstream (grid.cpp:31) so they cannot collide
+ * with BLACS contexts.
+ *
+ * The MPI-typed entry points exist only when the library was built with DLAF_MI355X_WITH_MPI
+ * (libdlaf_mi355x_mpi.so); the MI355X build talks RCCL over xGMI, so a grid can also be made
+ * without MPI through include/dlaf_mi355x/dlaf_mi355x.h (dlaf_mi355x_create_grid_rccl). */
+#pragma once
+#include <dlaf_c/utils.h>
+
+#ifdef DLAF_MI355X_WITH_MPI
+#include <mpi.h>
+/* reference: grid.h:31 -- order 'R' (row-major) or 'C' (column-major) rank placement */
+DLAF_EXTERN_C int dlaf_create_grid(MPI_Comm comm, int nprow, int npcol, char order) DLAF_NOEXCEPT;
+/* reference: grid.h:54 */
+DLAF_EXTERN_C char grid_ordering(MPI_Comm comm, int nprow, int npcol, int myprow, int mypcol) DLAF_NOEXCEPT;
+#endif
+
+/* reference: grid.h:39 */
+DLAF_EXTERN_C void dlaf_free_grid(int context) DLAF_NOEXCEPT;

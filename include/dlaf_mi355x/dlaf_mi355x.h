@@ -1,0 +1,97 @@
+/* dlaf_mi355x.h -- extensions of the C interface that the MI355X build adds next to the
+ * reference's dlaf_c/ headers.  Plain C ABI: pointers, sizes, chars; no C++ or torch types.
+ *
+ *   - MPI-free grids over RCCL/xGMI or over caller-supplied host broadcasts,
+ *   - a device-resident matrix handle so a driver can time the factorization with the matrix
+ *     already in HBM (what the reference's miniapp does with MatrixMirror,
+ *     miniapp/miniapp_cholesky.cpp:133-155),
+ *   - the synthetic input of the miniapp (include/dlaf/util_matrix.h:498-501),
+ *   - the four tile operations with exactly the argument sets the factorization issues
+ *     (include/dlaf/factorization/cholesky/impl.h:45-147), for known-answer tests,
+ *   - the 2-D block-cyclic index helpers (include/dlaf/matrix/util_distribution.h:82-196).
+ *
+ * type is one of 's' 'd' 'c' 'z'; uplo 'L' or 'U'.  Functions returning int return 0 on success,
+ * a negative value for an invalid argument, or a positive LAPACK info. */
+#pragma once
+#include <stddef.h>
+
+#include <dlaf_c/desc.h>
+#include <dlaf_c/utils.h>
+
+/* ---- grids --------------------------------------------------------------------------------- */
+/* 1x1 grid in this process (no communication).  Returns a context. */
+DLAF_EXTERN_C int dlaf_mi355x_create_grid_single(void) DLAF_NOEXCEPT;
+
+/* RCCL: rank 0 calls dlaf_mi355x_rccl_unique_id and ships the 128 bytes to every rank by any
+ * means (torch.distributed, MPI, a file); then every rank calls dlaf_mi355x_create_grid_rccl.
+ * order 'R': rank = myrow*npcol + mycol, 'C': rank = mycol*nprow + myrow
+ * (reference: common/index2d.h:345-355, dlaf_create_grid's order argument). */
+#define DLAF_MI355X_UNIQUE_ID_BYTES 128
+DLAF_EXTERN_C void dlaf_mi355x_rccl_unique_id(void* out_128_bytes) DLAF_NOEXCEPT;
+DLAF_EXTERN_C int dlaf_mi355x_create_grid_rccl(const void* unique_id_128_bytes, int nranks, int rank, int nprow,
+                                               int npcol, char order) DLAF_NOEXCEPT;
+
+/* Host-staged transport: the library hands a pinned HOST buffer to `bcast`, which must broadcast
+ * it from member `root` of this process's row (axis 0) or column (axis 1) communicator -- root is
+ * the process column index for axis 0 and the process row index for axis 1 -- and return 0. */
+typedef int (*dlaf_mi355x_bcast_fn)(void* user, int axis, int root, void* host_buf, size_t bytes);
+typedef int (*dlaf_mi355x_barrier_fn)(void* user);
+DLAF_EXTERN_C int dlaf_mi355x_create_grid_host(int nranks, int rank, int nprow, int npcol, char order,
+                                               dlaf_mi355x_bcast_fn bcast, dlaf_mi355x_barrier_fn barrier,
+                                               void* user) DLAF_NOEXCEPT;
+
+/* my coordinates in a grid; returns 0, or -1 for an unknown context */
+DLAF_EXTERN_C int dlaf_mi355x_grid_info(int context, int* nprow, int* npcol, int* myrow, int* mycol) DLAF_NOEXCEPT;
+
+/* ---- device-resident matrices -------------------------------------------------------------- */
+typedef struct dlaf_mi355x_matrix_s* dlaf_mi355x_matrix_t;
+
+/* desc.ld is ignored here (the device copy is in tile layout) */
+DLAF_EXTERN_C int dlaf_mi355x_matrix_create(int context, char type, char uplo, struct DLAF_descriptor desc,
+                                            dlaf_mi355x_matrix_t* out) DLAF_NOEXCEPT;
+DLAF_EXTERN_C void dlaf_mi355x_matrix_destroy(dlaf_mi355x_matrix_t m) DLAF_NOEXCEPT;
+/* host_local: this process's local column-major array with leading dimension ld */
+DLAF_EXTERN_C int dlaf_mi355x_matrix_upload(dlaf_mi355x_matrix_t m, const void* host_local, int ld) DLAF_NOEXCEPT;
+DLAF_EXTERN_C int dlaf_mi355x_matrix_download(dlaf_mi355x_matrix_t m, void* host_local, int ld) DLAF_NOEXCEPT;
+DLAF_EXTERN_C int dlaf_mi355x_matrix_copy(dlaf_mi355x_matrix_t dst, dlaf_mi355x_matrix_t src) DLAF_NOEXCEPT;
+/* enqueue the factorization / wait for it (returns info) / both */
+DLAF_EXTERN_C int dlaf_mi355x_cholesky_start(dlaf_mi355x_matrix_t m) DLAF_NOEXCEPT;
+DLAF_EXTERN_C int dlaf_mi355x_cholesky_wait(dlaf_mi355x_matrix_t m) DLAF_NOEXCEPT;
+DLAF_EXTERN_C int dlaf_mi355x_cholesky_factorization_device(dlaf_mi355x_matrix_t m) DLAF_NOEXCEPT;
+/* barrier over the matrix's grid (RCCL all-reduce / host callback) */
+DLAF_EXTERN_C int dlaf_mi355x_grid_barrier(int context) DLAF_NOEXCEPT;
+
+/* ---- synthetic input ------------------------------------------------------------------------ */
+/* Fills this process's local array (column-major, ld) of the n x n matrix with the reference's
+ * random Hermitian positive definite matrix: per global tile a std::mt19937_64 seeded with the
+ * tile's origin, uniform(-1,1) off the diagonal, 2n added on it (util_matrix.h:323-442,498-501).
+ * nthreads <= 0: all hardware threads. */
+DLAF_EXTERN_C int dlaf_mi355x_set_random_hpd(int context, char type, void* host_local,
+                                             struct DLAF_descriptor desc, int nthreads) DLAF_NOEXCEPT;
+
+/* ---- tile operations (host operands, column-major) -------------------------------------------- */
+/* potrf: returns LAPACK info (reference: lapack/tile.h:362-378) */
+DLAF_EXTERN_C int dlaf_mi355x_tile_potrf(char type, char uplo, int n, void* a, int lda) DLAF_NOEXCEPT;
+/* trsm: uplo L: B(m x n) <- B A^-H, A n x n lower;  uplo U: B <- A^-H B, A m x m upper
+ * (Right/Lower/ConjTrans and Left/Upper/ConjTrans, NonUnit, alpha 1: impl.h:56-67,:110-121) */
+DLAF_EXTERN_C int dlaf_mi355x_tile_trsm(char type, char uplo, int m, int n, const void* a, int lda, void* b,
+                                        int ldb) DLAF_NOEXCEPT;
+/* herk: uplo L: lower(C) -= A A^H, A n x k;  uplo U: upper(C) -= A^H A, A k x n (impl.h:70-80,:124-134) */
+DLAF_EXTERN_C int dlaf_mi355x_tile_herk(char type, char uplo, int n, int k, const void* a, int lda, void* c,
+                                        int ldc) DLAF_NOEXCEPT;
+/* gemm: uplo L: C(m x n) -= A B^H, A m x k, B n x k;  uplo U: C -= A^H B, A k x m, B k x n
+ * (impl.h:83-94,:137-147) */
+DLAF_EXTERN_C int dlaf_mi355x_tile_gemm(char type, char uplo, int m, int n, int k, const void* a, int lda,
+                                        const void* b, int ldb, void* c, int ldc) DLAF_NOEXCEPT;
+
+/* ---- index helpers (no GPU needed) -------------------------------------------------------------- */
+DLAF_EXTERN_C int dlaf_mi355x_dist_owner(long global_tile, int grid_size, int src_rank) DLAF_NOEXCEPT;
+DLAF_EXTERN_C long dlaf_mi355x_dist_local_tile(long global_tile, int grid_size, int rank, int src_rank) DLAF_NOEXCEPT;
+DLAF_EXTERN_C long dlaf_mi355x_dist_next_local_tile(long global_tile, int grid_size, int rank,
+                                                    int src_rank) DLAF_NOEXCEPT;
+DLAF_EXTERN_C long dlaf_mi355x_dist_global_tile(long local_tile, int grid_size, int rank, int src_rank) DLAF_NOEXCEPT;
+DLAF_EXTERN_C long dlaf_mi355x_dist_local_size(long n, int nb, int grid_size, int rank, int src_rank) DLAF_NOEXCEPT;
+DLAF_EXTERN_C long dlaf_mi355x_dist_local_tiles(long n, int nb, int grid_size, int rank, int src_rank) DLAF_NOEXCEPT;
+
+/* library identification: "dlaf_mi355x <version> gfx950" */
+DLAF_EXTERN_C const char* dlaf_mi355x_version(void) DLAF_NOEXCEPT;

@@ -1,0 +1,125 @@
+"""GPU parity tests of the factorization through the reference's entry points
+(test/unit/factorization/test_cholesky.cpp:54-120, test/unit/c_api/factorization/
+test_cholesky_c_api.cpp:62-155), against the analytic answer, the oracle and the miniapp's
+residual bar (miniapp/miniapp_cholesky.cpp:432-442)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TYPES = ["d", "z", "s", "c"]
+CHOLESKY_SIZES = [(0, 2), (5, 8), (34, 34), (4, 3), (16, 10), (34, 13), (32, 5)]
+
+
+@pytest.fixture(scope="module")
+def dlaf():
+    import dla_future_amd as d
+    d.initialize()
+    return d
+
+
+@pytest.fixture(scope="module")
+def grid(dlaf):
+    return dlaf.Grid.single()
+
+
+def err_of(orc, t):
+    return (8 if t in "cz" else 2) * orc.eps_of(orc.DTYPES[t])
+
+
+@pytest.mark.parametrize("t", TYPES)
+@pytest.mark.parametrize("uplo", ["L", "U"])
+def test_cholesky_local_analytic(dlaf, grid, oracle, t, uplo):
+    for m, mb in CHOLESKY_SIZES + [(150, 64), (200, 70), (333, 128)]:
+        a, l = oracle.cholesky_setters(uplo, m, oracle.DTYPES[t])
+        store = np.full((max(1, m) + 3, max(1, m)), 4.4, dtype=a.dtype, order="F")
+        store[:m, :m] = a
+        assert dlaf.cholesky_factorization(grid, uplo, store[:m, :m], mb) == 0
+        tol = 4 * (m + 1) * err_of(oracle, t)
+        ok, md = oracle.check_near(l, store[:m, :m], tol, tol)  # includes the untouched -9.9 triangle
+        assert ok, (m, mb, md)
+        assert (store[m:, :] == 4.4).all()
+
+
+@pytest.mark.parametrize("t", TYPES)
+@pytest.mark.parametrize("uplo", ["L", "U"])
+def test_cholesky_random_vs_oracle(dlaf, grid, oracle, t, uplo):
+    for n, nb in [(300, 64), (515, 128), (1024, 256)]:
+        dt = oracle.DTYPES[t]
+        a0 = oracle.set_random_hpd(n, nb, dt)
+        ref = a0.copy(order="F")
+        assert oracle.cholesky_local(uplo, ref, nb) == 0
+        got = a0.copy(order="F")
+        assert dlaf.cholesky_factorization(grid, uplo, got, nb) == 0
+        tol = 4 * (n + 1) * err_of(oracle, t)
+        ok, md = oracle.check_near(oracle.tri(uplo, ref), oracle.tri(uplo, got), tol, tol)
+        assert ok, (n, nb, md)
+        other = np.triu(got, 1) if uplo == "L" else np.tril(got, -1)
+        other0 = np.triu(a0, 1) if uplo == "L" else np.tril(a0, -1)
+        assert np.array_equal(other, other0)
+        assert oracle.cholesky_residual(uplo, a0, got) <= n * oracle.eps_of(dt)
+
+
+def test_generator_matches_oracle(dlaf, grid, oracle):
+    for t in TYPES:
+        dt = oracle.DTYPES[t]
+        for n, nb in [(34, 13), (100, 32)]:
+            a = np.zeros((n, n), dtype=dt, order="F")
+            dlaf.set_random_hermitian_positive_definite(grid, a, n, nb)
+            assert np.array_equal(a, oracle.set_random_hpd(n, nb, dt)), (t, n, nb)
+
+
+def test_pdpotrf_scalapack_entry(dlaf, grid, oracle):
+    # test_cholesky_c_api.cpp:108-155: same matrices through dlaf_p?potrf
+    for t in TYPES:
+        n, nb = 130, 32
+        a0 = oracle.set_random_hpd(n, nb, oracle.DTYPES[t])
+        a = a0.copy(order="F")
+        desca = [1, grid.context, n, n, nb, nb, 0, 0, n]
+        assert dlaf.pxpotrf("L", n, a, 1, 1, desca) == 0
+        ref = a0.copy(order="F")
+        oracle.cholesky_local("L", ref, nb)
+        tol = 4 * (n + 1) * err_of(oracle, t)
+        ok, md = oracle.check_near(np.tril(ref), np.tril(a), tol, tol)
+        assert ok, (t, md)
+
+
+def test_non_spd_reports_lapack_info(dlaf, grid, oracle):
+    n, nb = 400, 128
+    a = oracle.set_random_hpd(n, nb, np.float64)
+    a[300, 300] = -1.0
+    assert dlaf.cholesky_factorization(grid, "L", a.copy(order="F"), nb) == 301
+    assert dlaf.cholesky_factorization(grid, "U", a.copy(order="F"), nb) == 301
+
+
+def test_device_resident_repeatable(dlaf, grid, oracle):
+    """miniapp pattern: upload once, copy the pristine matrix, factorize, repeat -> identical bits."""
+    n, nb = 1024, 256
+    a0 = oracle.set_random_hpd(n, nb, np.float64)
+    ref = dlaf.DeviceMatrix(grid, np.float64, "L", n, nb)
+    work = dlaf.DeviceMatrix(grid, np.float64, "L", n, nb)
+    ref.upload(a0)
+    outs = []
+    for _ in range(2):
+        work.copy_from(ref)
+        assert work.factorize() == 0
+        out = a0.copy(order="F")
+        work.download(out)
+        outs.append(out)
+    assert np.array_equal(outs[0], outs[1])
+    assert oracle.cholesky_residual("L", a0, outs[0]) <= n * np.finfo(np.float64).eps
+
+
+@pytest.mark.parametrize("t", ["d", "z"])
+def test_larger_property_checks(dlaf, grid, oracle, t):
+    """Size-independent properties at a size the oracle cannot factor in seconds: residual bar of the
+    miniapp, positivity of the diagonal, untouched opposite triangle."""
+    n, nb = (4096, 512) if t == "d" else (2048, 256)
+    dt = oracle.DTYPES[t]
+    a0 = np.zeros((n, n), dtype=dt, order="F")
+    dlaf.set_random_hermitian_positive_definite(grid, a0, n, nb)
+    a = a0.copy(order="F")
+    assert dlaf.cholesky_factorization(grid, "L", a, nb) == 0
+    assert (np.diag(a).real > 0).all() and (np.diag(a).imag == 0).all()
+    assert np.array_equal(np.triu(a, 1), np.triu(a0, 1))
+    assert oracle.cholesky_residual("L", a0, a) <= n * oracle.eps_of(dt)
