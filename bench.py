@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- fp64 tiled Cholesky TFlop/s on N MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step is ONE factorization of the synthetic SPD matrix (set_random_hermitian_positive_definite,
+include/dlaf/util_matrix.h:498-501) that is already resident in HBM in tile layout when the
+timed region starts -- the window of the reference's miniapp (miniapp/miniapp_cholesky.cpp:137-155).
+Default workload: the configuration the metric is quoted on, d N=65536 nb=1024 uplo=L, which fits one
+GPU (32 GiB); grids 1x1, 1x2, 2x2, 2x4 (column-major rank order like the miniapp, :113).
+Flop model: N^3/3 (miniapp_cholesky.cpp:157-162).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# MI355X fp64 matrix peak: 256 CU x 4 SIMD x (16x16x4 MFMA = 2048 flop / 64 cycles) x 2.4 GHz
+# = 78.6 TFlop/s (vendor datasheet figure; issue rate confirmed by tools/mfma_f64_rate.hip)
+PEAK_FP64_MFMA_TFLOPS = 78.6
+GRIDS = {1: (1, 1), 2: (1, 2), 4: (2, 2), 8: (2, 4), 3: (1, 3), 6: (2, 3)}
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--n", type=int, default=65536)
+    p.add_argument("--nb", type=int, default=1024)
+    p.add_argument("--type", default="d", choices=["s", "d", "c", "z"])
+    p.add_argument("--uplo", default="L", choices=["L", "U"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-n", type=int, default=8192)
+    p.add_argument("--cpu-nb", type=int, default=256)
+    p.add_argument("--check", action="store_true", help="download and check the residual of the last run (N <= 16384)")
+    return p.parse_args()
+
+
+def cpu_baseline(args):
+    """The oracle's tile-DAG port (oracle/dlaf_oracle.c: orc_baseline_cholesky_d) timed on this box's
+    host cores on a bounded sample of the same workload.  Checker code, used here ONLY as the reported
+    CPU baseline."""
+    from oracle import oracle
+    n, nb = args.cpu_n, args.cpu_nb
+    threads = max(1, min(len(os.sched_getaffinity(0)), 64))
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    a = oracle.set_random_hpd(n, nb, np.float64)
+    t0 = time.perf_counter()
+    info = oracle.baseline_cholesky_d(a, nb, threads)
+    dt = time.perf_counter() - t0
+    assert info == 0
+    return {"value": (n ** 3 / 3) / dt / 1e12, "unit": "TFlop/s", "cores": threads, "kind": "port",
+            "sample": f"fp64 lower Cholesky N={n} nb={nb}, same generator, oracle tile-DAG (OpenMP tasks, "
+                      f"register-blocked C tile kernels), {dt:.2f} s wall"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: dla_future_amd has no CPU path")
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank % torch.cuda.device_count()))
+
+    import dla_future_amd as dlaf
+    dlaf.initialize()
+    nprow, npcol = GRIDS.get(world, (1, world))
+    grid = dlaf.Grid.from_torch(nprow, npcol, "C") if world > 1 else dlaf.Grid.single()
+
+    n, nb = args.n, args.nb
+    dt = {"s": np.float32, "d": np.float64, "c": np.complex64, "z": np.complex128}[args.type]
+    lrows, lcols = grid.local_shape(n, nb)
+    t_gen = time.perf_counter()
+    a = np.zeros((max(1, lrows), max(1, lcols)), dtype=dt, order="F")[:lrows, :lcols]
+    dlaf.set_random_hermitian_positive_definite(grid, a, n, nb)
+    t_gen = time.perf_counter() - t_gen
+    ref = dlaf.DeviceMatrix(grid, dt, args.uplo, n, nb)
+    t_up = time.perf_counter()
+    ref.upload(a)
+    t_up = time.perf_counter() - t_up
+    a_keep = a if args.check else None
+    del a
+
+    # one work matrix per timed step when HBM allows it, so that no restore copy sits inside the
+    # timed region (the miniapp takes a fresh copy of the input outside its timer, :133-141)
+    local_bytes = lrows * lcols * np.dtype(dt).itemsize
+    free_b, _total = torch.cuda.mem_get_info()
+    npool = max(1, min(args.steps, int((free_b * 0.8) // max(local_bytes * 1.05, 1))))
+    pool = [dlaf.DeviceMatrix(grid, dt, args.uplo, n, nb) for _ in range(npool)]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        pool[0].copy_from(ref)
+        info = pool[0].factorize()
+        assert info == 0, info
+    for w in pool:
+        w.copy_from(ref)
+
+    prof = {k: {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0} for k in dlaf.DeviceMatrix.PROFILE_KINDS}
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        w = pool[s % npool]
+        if s >= npool:
+            w.copy_from(ref)  # restore inside the timed region only when HBM could not hold K copies
+        info = w.factorize()
+        assert info == 0, info
+        for k in prof:
+            p = w.profile(k)
+            for f in prof[k]:
+                prof[k][f] += p[f]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    flops = (4.0 if args.type in "cz" else 1.0) * n ** 3 / 3.0
+    sec_per_step = elapsed / args.steps
+    tflops = flops / sec_per_step / 1e12
+
+    check = None
+    if args.check and world == 1 and n <= 16384:
+        from oracle import oracle
+        out = a_keep.copy(order="F")
+        pool[(args.steps - 1) % npool].download(out)
+        check = oracle.cholesky_residual(args.uplo, a_keep, out)
+
+    if rank == 0:
+        bulk = prof["update_bulk"]
+        trsm = prof["trsm_panel"]
+        ach = bulk["flops"] / (bulk["ms"] * 1e-3) / 1e12 if bulk["ms"] > 0 else 0.0
+        line = {
+            "metric": "fp64 Cholesky TFlop/s" if args.type == "d" else f"{args.type} Cholesky TFlop/s",
+            "value": round(tflops, 4), "unit": "TFlop/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(sec_per_step * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": {"s": "f32", "d": "f64", "c": "c64", "z": "c128"}[args.type],
+            "data": "synthetic",
+            "config": {"workload": f"cholesky_{args.type} N={n} nb={nb} uplo={args.uplo}", "grid": f"{nprow}x{npcol}",
+                       "rank_order": "column-major", "work_copies": npool,
+                       "restore_in_timed_region": bool(args.steps > npool)},
+            "fraction_of_fp64_mfma_peak": round(tflops / (world * PEAK_FP64_MFMA_TFLOPS), 4),
+            "roofline": {"kernel": "update_kernel<T,VEC,0> (grouped trailing herk+gemm)", "bound": "mfma",
+                         "achieved": round(ach, 3), "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFlop/s",
+                         "frac": round(ach / PEAK_FP64_MFMA_TFLOPS, 4), "traffic": None,
+                         "launches": bulk["launches"], "avg_launch_ms": round(bulk["ms"] / max(1, bulk["launches"]), 4),
+                         "algorithmic_flop_per_launch": bulk["flops"] / max(1, bulk["launches"])},
+            "trsm_panel": {"bound": "hbm", "achieved_GBps": round(trsm["bytes"] / max(trsm["ms"], 1e-9) / 1e6, 1),
+                           "achieved_TFlops": round(trsm["flops"] / max(trsm["ms"], 1e-9) / 1e9, 3),
+                           "launches": trsm["launches"], "avg_launch_ms": round(trsm["ms"] / max(1, trsm["launches"]), 4)},
+            "potrf_tile": {"launches": prof["potrf_tile"]["launches"],
+                           "avg_ms": round(prof["potrf_tile"]["ms"] / max(1, prof["potrf_tile"]["launches"]), 4)},
+            "setup": {"generate_s": round(t_gen, 2), "upload_s": round(t_up, 2)},
+        }
+        if check is not None:
+            line["residual"] = check
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                line["cpu_baseline"] = cpu_baseline(args)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                line["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

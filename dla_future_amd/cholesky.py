@@ -200,6 +200,15 @@ class DeviceMatrix:
     def wait(self) -> int:
         return lib().dlaf_mi355x_cholesky_wait(self._h)
 
+    PROFILE_KINDS = {"update_bulk": 0, "update_lookahead": 1, "trsm_panel": 2, "potrf_tile": 3}
+
+    def profile(self, kind: str) -> dict:
+        """HIP-event timing of one launch class of the last factorization (after wait())."""
+        ms, n, fl, by = C.c_double(), C.c_long(), C.c_double(), C.c_double()
+        lib().dlaf_mi355x_matrix_profile(self._h, self.PROFILE_KINDS[kind], C.byref(ms), C.byref(n), C.byref(fl),
+                                         C.byref(by))
+        return {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
+
     def close(self) -> None:
         if self._h:
             lib().dlaf_mi355x_matrix_destroy(self._h)

@@ -37,8 +37,9 @@ struct UpdateArgs {
   int nt, last_rows;
   const int* info;  // device flag: non-zero => a previous POTRF failed, kernels return at once
 };
+// role: 0 trailing bulk, 1 lookahead column, 2 in-tile POTRF update (same code, separate kernel names)
 template <class T>
-void launch_update(const UpdateArgs<T>& args, hipStream_t stream);
+void launch_update(const UpdateArgs<T>& args, hipStream_t stream, int role = 0);
 
 // ------------------------------------------------------------------------------------------
 // Panel TRSM (tile::trsm Right/Lower/ConjTrans/NonUnit of a whole panel in ONE launch,

@@ -10,6 +10,8 @@
 //   * herk is the same code with a lower-triangle mask on diagonal tiles (and a real diagonal
 //     for complex types).
 // Roofline: MFMA-bound, 2*nb^3 flop per 4*nb^2*sizeof(T) algorithmic bytes per tile.
+#include <type_traits>
+
 #include "device_api.hpp"
 #include "mma_core.hpp"
 
@@ -47,7 +49,9 @@ struct UpdateMap {
   int bpt_m, bpt_n;
 };
 
-template <class T, bool VEC>
+// ROLE only names the instantiation (0 trailing bulk, 1 lookahead column, 2 in-tile POTRF update) so
+// that rocprof statistics and the library's own HIP-event timing refer to the same set of launches
+template <class T, bool VEC, int ROLE>
 __global__ __launch_bounds__(kThreads, UpdateCfg<T>::min_waves) void update_kernel(UpdateArgs<T> p, UpdateMap mp) {
   using Cfg = typename UpdateCfg<T>::type;
   using R = real_t<T>;
@@ -155,7 +159,7 @@ static bool aligned16(const void* ptr, long stride_elems) {
 }
 
 template <class T>
-void launch_update(const UpdateArgs<T>& a, hipStream_t stream) {
+void launch_update(const UpdateArgs<T>& a, hipStream_t stream, int role) {
   using Cfg = typename UpdateCfg<T>::type;
   if (a.il1 <= a.il0 || a.jl1 <= a.jl0 || a.K <= 0 || a.nb <= 0)
     return;
@@ -174,19 +178,37 @@ void launch_update(const UpdateArgs<T>& a, hipStream_t stream) {
   mp.xcd = (mp.ps > 0) ? 1 : 0;
   const bool vec = aligned16<T>(a.a, a.lda) && aligned16<T>(a.a, a.a_ts) && aligned16<T>(a.b, a.ldb) &&
                    aligned16<T>(a.b, a.b_ts);
+  auto go = [&](auto vtag, auto rtag) {
+    constexpr bool V = decltype(vtag)::value;
+    constexpr int RL = decltype(rtag)::value;
+    hipLaunchKernelGGL((update_kernel<T, V, RL>), dim3((unsigned) grid), dim3(kThreads), Cfg::LDS_BYTES, stream, a, mp);
+  };
+  auto by_role = [&](auto vtag) {
+    switch (role) {
+      case 0: go(vtag, std::integral_constant<int, 0>{}); break;
+      case 1: go(vtag, std::integral_constant<int, 1>{}); break;
+      default: go(vtag, std::integral_constant<int, 2>{}); break;
+    }
+  };
   if (vec)
-    hipLaunchKernelGGL((update_kernel<T, true>), dim3((unsigned) grid), dim3(kThreads), Cfg::LDS_BYTES, stream, a, mp);
+    by_role(std::true_type{});
   else
-    hipLaunchKernelGGL((update_kernel<T, false>), dim3((unsigned) grid), dim3(kThreads), Cfg::LDS_BYTES, stream, a, mp);
+    by_role(std::false_type{});
 }
 
 template <class T>
 static void update_init_one() {
   using Cfg = typename UpdateCfg<T>::type;
-  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&update_kernel<T, true>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&update_kernel<T, false>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+#define SET_ONE(V, RL)                                                                         \
+  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&update_kernel<T, V, RL>),           \
+                             hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES)
+  SET_ONE(true, 0);
+  SET_ONE(true, 1);
+  SET_ONE(true, 2);
+  SET_ONE(false, 0);
+  SET_ONE(false, 1);
+  SET_ONE(false, 2);
+#undef SET_ONE
 }
 
 void update_kernels_init() {
@@ -196,9 +218,9 @@ void update_kernels_init() {
   update_init_one<cdouble>();
 }
 
-template void launch_update<float>(const UpdateArgs<float>&, hipStream_t);
-template void launch_update<double>(const UpdateArgs<double>&, hipStream_t);
-template void launch_update<cfloat>(const UpdateArgs<cfloat>&, hipStream_t);
-template void launch_update<cdouble>(const UpdateArgs<cdouble>&, hipStream_t);
+template void launch_update<float>(const UpdateArgs<float>&, hipStream_t, int);
+template void launch_update<double>(const UpdateArgs<double>&, hipStream_t, int);
+template void launch_update<cfloat>(const UpdateArgs<cfloat>&, hipStream_t, int);
+template void launch_update<cdouble>(const UpdateArgs<cdouble>&, hipStream_t, int);
 
 }  // namespace dlaf_mi355x

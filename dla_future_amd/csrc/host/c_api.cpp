@@ -334,6 +334,14 @@ int dlaf_mi355x_cholesky_factorization_device(dlaf_mi355x_matrix_t h) noexcept {
   WITH_MATRIX(h, return M.factorize();)
 }
 
+int dlaf_mi355x_matrix_profile(dlaf_mi355x_matrix_t h, int kind, double* ms, long* launches, double* flops,
+                               double* bytes) noexcept {
+  if (kind < 0 || kind > 3)
+    return -2;
+  WITH_MATRIX(h, const auto& p = M.prof[kind]; if (ms) *ms = p.ms; if (launches) *launches = p.launches;
+              if (flops) *flops = p.flops; if (bytes) *bytes = p.bytes; return 0;)
+}
+
 int dlaf_mi355x_set_random_hpd(int ctx, char type, void* host, DLAF_descriptor d, int nthreads) noexcept {
   auto it = g_grids.find(ctx);
   if (it == g_grids.end())

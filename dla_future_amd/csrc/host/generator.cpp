@@ -5,8 +5,7 @@
 // the block-cyclic matrix.  Like the reference it draws from std::mt19937_64 through
 // std::uniform_real_distribution<T>(-1, 1): the values are therefore those of the C++ standard
 // library this file is built with (libstdc++ here, as upstream).  The complex sample
-// polar(|draw|, pi*draw) is written with the two draws as function arguments exactly as upstream,
-// i.e. with the compiler's evaluation order (g++: right to left).
+// polar(|draw|, pi*draw) has its two draws pinned to g++'s order (see Getter<std::complex<T>>).
 #include <cmath>
 #include <complex>
 #include <random>
@@ -34,7 +33,12 @@ class Getter<std::complex<T>> : private Getter<T> {
 public:
   using Getter<T>::Getter;
   std::complex<T> operator()() {
-    return std::polar<T>(std::abs(Getter<T>::operator()()), static_cast<T>(M_PI) * Getter<T>::operator()());
+    // upstream passes both draws as function arguments (unspecified order).  g++ evaluates them right
+    // to left -- first draw = angle, second = magnitude -- and that order is fixed here so that every
+    // compiler (this file is built with hipcc/clang) generates the same matrix as the test oracle.
+    const T angle = Getter<T>::operator()();
+    const T magnitude = Getter<T>::operator()();
+    return std::polar<T>(std::abs(magnitude), static_cast<T>(M_PI) * angle);
   }
 };
 

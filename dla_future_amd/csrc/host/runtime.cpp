@@ -176,6 +176,14 @@ void DeviceMatrix<T>::destroy() {
       (void) hipEventDestroy(e);
     v->clear();
   }
+  for (auto& ps : prof) {
+    for (auto e : ps.start)
+      (void) hipEventDestroy(e);
+    for (auto e : ps.stop)
+      (void) hipEventDestroy(e);
+    ps.start.clear();
+    ps.stop.clear();
+  }
   (void) hipStreamDestroy(s_high);
   (void) hipStreamDestroy(s_low);
   (void) hipStreamDestroy(s_comm);
@@ -272,6 +280,32 @@ void DeviceMatrix<T>::copy_from(const DeviceMatrix<T>& o) {
   DLAF_HIP_CHECK(hipStreamSynchronize(s_high));
 }
 
+template <class T>
+void DeviceMatrix<T>::prof_begin(int kind, hipStream_t s) {
+  if (!profiling)
+    return;
+  ProfSlot& p = prof[kind];
+  if (p.used == p.start.size()) {
+    hipEvent_t a, b;
+    DLAF_HIP_CHECK(hipEventCreate(&a));
+    DLAF_HIP_CHECK(hipEventCreate(&b));
+    p.start.push_back(a);
+    p.stop.push_back(b);
+  }
+  DLAF_HIP_CHECK(hipEventRecord(p.start[p.used], s));
+}
+
+template <class T>
+void DeviceMatrix<T>::prof_end(int kind, hipStream_t s, double flops, double bytes) {
+  if (!profiling)
+    return;
+  ProfSlot& p = prof[kind];
+  DLAF_HIP_CHECK(hipEventRecord(p.stop[p.used], s));
+  ++p.used;
+  p.flops += flops;
+  p.bytes += bytes;
+}
+
 // ------------------------------------------------------------------------------- tile POTRF
 // Blocked lower Cholesky of one kb x kb tile (ld) with inner block 64: diagonal block kernel,
 // sub-panel solve (TRSM kernel, one column block), in-tile trailing update (update kernel).
@@ -325,7 +359,7 @@ static void potrf_tile(T* t, int ld, int kb, T* winv, int* info, int info_base, 
     ua.nt = 1;
     ua.last_rows = rem;
     ua.info = info;
-    launch_update(ua, s);
+    launch_update(ua, s, 2);
   }
 }
 
@@ -349,13 +383,41 @@ void DeviceMatrix<T>::factorize_async() {
   const CommAxis ax_row = transposed ? CommAxis::Col : CommAxis::Row;
   const CommAxis ax_col = transposed ? CommAxis::Row : CommAxis::Col;
 
+  for (auto& ps : prof) {
+    ps.used = 0;
+    ps.flops = ps.bytes = ps.ms = 0;
+    ps.launches = 0;
+  }
   DLAF_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int), s_high));
   DLAF_HIP_CHECK(hipEventRecord(ev_bcastT[0], s_high));
   DLAF_HIP_CHECK(hipStreamWaitEvent(s_low, ev_bcastT[0], 0));
   DLAF_HIP_CHECK(hipStreamWaitEvent(s_comm, ev_bcastT[0], 0));
 
+  // algorithmic work of one grouped update launch (BASELINE.md roofline table):
+  // gemm tile 2 m n k flop / (m k + n k + 2 m n) elements, herk tile n (n+1) k flop / (n k + n^2) elements
+  auto update_work = [&](long il0, long j0, long j1, int kb, double& flops, double& bytes) {
+    flops = bytes = 0;
+    const double cx = TypeInfo<T>::is_complex ? 4.0 : 1.0;
+    for (long jl = j0; jl < j1; ++jl) {
+      const long gj = cols.global_of(jl);
+      const double nj = rows.tile_extent(gj);
+      for (long il = std::max(il0, rows.next_local(gj)); il < ltr; ++il) {
+        const long gi = rows.global_of(il);
+        const double mi = rows.tile_extent(gi);
+        if (gi == gj) {
+          flops += cx * mi * (mi + 1) * kb;
+          bytes += (mi * kb + mi * mi) * sizeof(T);
+        }
+        else {
+          flops += cx * 2.0 * mi * nj * kb;
+          bytes += (mi * kb + nj * kb + 2.0 * mi * nj) * sizeof(T);
+        }
+      }
+    }
+  };
+
   auto update = [&](const T* a_base, long a_il0, const T* b_base, long b_ts, long b_jl0, long j0, long j1,
-                    int kb, hipStream_t s) {
+                    int kb, hipStream_t s, int role) {
     if (j0 >= j1)
       return;
     // rows that can hold tiles on/below the diagonal of column block j0
@@ -386,7 +448,11 @@ void DeviceMatrix<T>::factorize_async() {
     ua.nt = (int) nt;
     ua.last_rows = last_rows;
     ua.info = info;
-    launch_update(ua, s);
+    double fl, by;
+    update_work(il0, j0, j1, kb, fl, by);
+    prof_begin(role, s);
+    launch_update(ua, s, role);
+    prof_end(role, s, fl, by);
   };
 
   for (long k = 0; k < nt; ++k) {
@@ -402,7 +468,10 @@ void DeviceMatrix<T>::factorize_async() {
     const T* Wkk = nullptr;
     if (in_row && in_col) {
       T* tkk = tile(rows.local_of(k), klc);
+      const double cxf = TypeInfo<T>::is_complex ? 4.0 : 1.0;
+      prof_begin(3, s_high);
       potrf_tile(tkk, nb, kb, winv, info, (int) (k * nb), s_high);
+      prof_end(3, s_high, cxf * (double) kb * kb * kb / 3.0, (double) kb * kb * sizeof(T));
       Lkk = tkk;
       Wkk = winv;
     }
@@ -443,7 +512,16 @@ void DeviceMatrix<T>::factorize_async() {
         ta.winv = Wkk;
         ta.n = kb;
         ta.info = info;
+        // algorithmic work: n^2 m flop and (n^2/2 + 2 m n) elements per tile
+        double fl = 0, by = 0;
+        for (long il = il_n; il < ltr; ++il) {
+          const double mi = rows.tile_extent(rows.global_of(il));
+          fl += (TypeInfo<T>::is_complex ? 4.0 : 1.0) * (double) kb * kb * mi;
+          by += (0.5 * kb * kb + 2.0 * mi * kb) * sizeof(T);
+        }
+        prof_begin(2, s_high);
         launch_trsm(ta, s_high);
+        prof_end(2, s_high, fl, by);
       }
     }
     DLAF_HIP_CHECK(hipEventRecord(ev_panel[k], s_high));
@@ -503,12 +581,12 @@ void DeviceMatrix<T>::factorize_async() {
       DLAF_HIP_CHECK(hipStreamWaitEvent(s_high, ev_low[k - 1], 0));
     long rest0 = jl_n;
     if (cols.mine(k + 1) && jl_n < ltc) {
-      update(a_base, il_n, b_base, b_ts, jl_n, jl_n, jl_n + 1, kb, s_high);
+      update(a_base, il_n, b_base, b_ts, jl_n, jl_n, jl_n + 1, kb, s_high, 1);
       rest0 = jl_n + 1;
     }
     DLAF_HIP_CHECK(hipEventRecord(ev_high[k], s_high));
     DLAF_HIP_CHECK(hipStreamWaitEvent(s_low, ev_panel[k], 0));
-    update(a_base, il_n, b_base, b_ts, jl_n, rest0, ltc, kb, s_low);
+    update(a_base, il_n, b_base, b_ts, jl_n, rest0, ltc, kb, s_low, 0);
     DLAF_HIP_CHECK(hipEventRecord(ev_low[k], s_low));
   }
   DLAF_HIP_CHECK(hipMemcpyAsync(info_host, info, sizeof(int), hipMemcpyDeviceToHost, s_high));
@@ -520,6 +598,15 @@ int DeviceMatrix<T>::wait() {
   DLAF_HIP_CHECK(hipStreamSynchronize(s_low));
   DLAF_HIP_CHECK(hipStreamSynchronize(s_high));
   DLAF_HIP_CHECK(hipMemcpy(info_host, info, sizeof(int), hipMemcpyDeviceToHost));
+  for (auto& ps : prof) {
+    ps.ms = 0;
+    ps.launches = (long) ps.used;
+    for (size_t i = 0; i < ps.used; ++i) {
+      float ms = 0;
+      DLAF_HIP_CHECK(hipEventElapsedTime(&ms, ps.start[i], ps.stop[i]));
+      ps.ms += ms;
+    }
+  }
   return *info_host;
 }
 

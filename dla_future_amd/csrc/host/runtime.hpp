@@ -98,6 +98,20 @@ struct DeviceMatrix : MatrixBase {
   hipStream_t s_high = nullptr, s_low = nullptr, s_comm = nullptr;
   std::vector<hipEvent_t> ev_panel, ev_low, ev_high, ev_diag, ev_bcast, ev_bcastT;
 
+  // live timing of the launch classes with HIP events on the stream each class runs on
+  // (kind 0: trailing bulk update, 1: lookahead-column update, 2: panel TRSM, 3: tile POTRF chain)
+  struct ProfSlot {
+    std::vector<hipEvent_t> start, stop;
+    size_t used = 0;
+    double flops = 0, bytes = 0;   // algorithmic, summed over the launches of the last run
+    double ms = 0;                 // filled by wait()
+    long launches = 0;
+  };
+  ProfSlot prof[4];
+  bool profiling = true;
+  void prof_begin(int kind, hipStream_t s);
+  void prof_end(int kind, hipStream_t s, double flops, double bytes);
+
   T* tile(long il, long jl) const { return tiles + (size_t) (il + jl * ltr) * tile_elems; }
   size_t winv_elems() const { return (size_t) ((nb + kDiagBlock - 1) / kDiagBlock) * kDiagBlock * kDiagBlock; }
 

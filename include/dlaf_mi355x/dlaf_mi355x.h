@@ -58,6 +58,12 @@ DLAF_EXTERN_C int dlaf_mi355x_matrix_copy(dlaf_mi355x_matrix_t dst, dlaf_mi355x_
 DLAF_EXTERN_C int dlaf_mi355x_cholesky_start(dlaf_mi355x_matrix_t m) DLAF_NOEXCEPT;
 DLAF_EXTERN_C int dlaf_mi355x_cholesky_wait(dlaf_mi355x_matrix_t m) DLAF_NOEXCEPT;
 DLAF_EXTERN_C int dlaf_mi355x_cholesky_factorization_device(dlaf_mi355x_matrix_t m) DLAF_NOEXCEPT;
+/* Live timing of the last factorization, measured with HIP events on the stream each launch class
+ * runs on.  kind 0: grouped trailing update (herk+gemm of columns > k+1), 1: lookahead-column update,
+ * 2: panel TRSM, 3: diagonal-tile POTRF chain.  ms = summed launch durations, flops / bytes = summed
+ * ALGORITHMIC work of those launches (BASELINE.md roofline table).  Call after *_wait. */
+DLAF_EXTERN_C int dlaf_mi355x_matrix_profile(dlaf_mi355x_matrix_t m, int kind, double* ms, long* launches,
+                                             double* flops, double* bytes) DLAF_NOEXCEPT;
 /* barrier over the matrix's grid (RCCL all-reduce / host callback) */
 DLAF_EXTERN_C int dlaf_mi355x_grid_barrier(int context) DLAF_NOEXCEPT;
 

@@ -66,7 +66,14 @@ def test_generator_matches_oracle(dlaf, grid, oracle):
         for n, nb in [(34, 13), (100, 32)]:
             a = np.zeros((n, n), dtype=dt, order="F")
             dlaf.set_random_hermitian_positive_definite(grid, a, n, nb)
-            assert np.array_equal(a, oracle.set_random_hpd(n, nb, dt)), (t, n, nb)
+            o = oracle.set_random_hpd(n, nb, dt)
+            if t in "sd":
+                assert np.array_equal(a, o), (t, n, nb)
+            else:
+                # polar() goes through libm's sin/cos: the product (clang) and the oracle (gcc) may pick
+                # sincos vs sin+cos, which differ in the last bit on some hosts
+                assert np.abs(a - o).max() <= 4 * oracle.eps_of(dt), (t, n, nb)
+                assert (a.real == o.real).mean() > 0.99
 
 
 def test_pdpotrf_scalapack_entry(dlaf, grid, oracle):
