@@ -155,7 +155,29 @@ void DeviceMatrix<T>::create(Grid* g, char uplo_, long n_, int nb_, int isrc, in
   int lo = 0, hi = 0;
   DLAF_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
   DLAF_HIP_CHECK(hipStreamCreateWithPriority(&s_high, hipStreamNonBlocking, hi));
-  DLAF_HIP_CHECK(hipStreamCreateWithPriority(&s_low, hipStreamNonBlocking, lo));
+  // Tuning knobs (tune.h analogue): DLAF_MI355X_SERIAL=1 issues everything on one stream (no
+  // lookahead); DLAF_MI355X_RESERVED_CUS=R keeps R compute units out of the bulk-update stream so
+  // the critical-path kernels (POTRF chain, panel TRSM) never queue behind long update workgroups.
+  const char* serial = std::getenv("DLAF_MI355X_SERIAL");
+  const char* rcu = std::getenv("DLAF_MI355X_RESERVED_CUS");
+  const int reserved = rcu ? std::atoi(rcu) : 0;
+  if (serial && std::atoi(serial) != 0) {
+    s_low = s_high;
+  }
+  else if (reserved > 0) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    DLAF_HIP_CHECK(hipGetDevice(&dev));
+    DLAF_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    const int ncu = prop.multiProcessorCount;
+    std::vector<uint32_t> mask((size_t) (ncu + 31) / 32, 0u);
+    for (int cu = reserved; cu < ncu; ++cu)
+      mask[(size_t) cu / 32] |= 1u << (cu % 32);
+    DLAF_HIP_CHECK(hipExtStreamCreateWithCUMask(&s_low, (uint32_t) mask.size(), mask.data()));
+  }
+  else {
+    DLAF_HIP_CHECK(hipStreamCreateWithPriority(&s_low, hipStreamNonBlocking, lo));
+  }
   DLAF_HIP_CHECK(hipStreamCreateWithPriority(&s_comm, hipStreamNonBlocking, hi));
   const size_t ne = (size_t) (nt > 0 ? nt : 1);
   ev_panel = make_events(ne);
@@ -184,8 +206,9 @@ void DeviceMatrix<T>::destroy() {
     ps.start.clear();
     ps.stop.clear();
   }
+  if (s_low != s_high)
+    (void) hipStreamDestroy(s_low);
   (void) hipStreamDestroy(s_high);
-  (void) hipStreamDestroy(s_low);
   (void) hipStreamDestroy(s_comm);
   (void) hipFree(tiles);
   (void) hipFree(winv);
