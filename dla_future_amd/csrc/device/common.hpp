@@ -119,13 +119,13 @@ constexpr int kLdsPad = 16;    // elements of padding per k-row of an LDS panel 
 // Global image: column-major, element (r, k) at src[r + k*ld].  LDS image: [k][ROWS+pad]
 // (k-major, rows contiguous), one plane for real types, re/im planes for complex.
 // VEC: 16-byte loads (needs src 16-B aligned, ld*sizeof(T) % 16 == 0); otherwise per element.
-template <class T, int ROWS, int BK, bool VEC>
+template <class T, int ROWS, int BK, bool VEC, int LD_ = ROWS + kLdsPad>
 struct Slab {
   using R = real_t<T>;
   static constexpr bool CX = TypeInfo<T>::is_complex;
   static constexpr int VE = VEC ? ((16 / (int) sizeof(T)) > 0 ? (16 / (int) sizeof(T)) : 1) : 1;
   static constexpr int NL = (ROWS * BK) / (kThreads * VE);
-  static constexpr int LD = ROWS + kLdsPad;
+  static constexpr int LD = LD_;
   static constexpr int PLANE = BK * LD;                  // elements of R per plane
   static constexpr int ELEMS = (CX ? 2 : 1) * PLANE;     // elements of R per slab image
   static_assert((ROWS * BK) % (kThreads * VE) == 0, "slab must divide over the workgroup");

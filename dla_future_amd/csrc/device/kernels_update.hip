@@ -26,7 +26,7 @@ struct UpdateCfg<float> {
 };
 template <>
 struct UpdateCfg<double> {
-  using type = BlockCfg<double, 128, 128, 64, 64, 16>;
+  using type = BlockCfg<double, 128, 128, 64, 64, 16, true>;
   static constexpr int min_waves = 2;
 };
 template <>
@@ -114,38 +114,86 @@ __global__ __launch_bounds__(kThreads, UpdateCfg<T>::min_waves) void update_kern
   else
     gemm_nt_block<Cfg, T, false, true>(A, p.lda, mrows, B, ldb, ncols, p.K, lds, acc);
 
+#ifdef DLAF_DBG_SKIP_EPILOGUE
+  {
+    R sum = 0;  // keep every accumulator live; the comparison is never true on real data
+    for (int i = 0; i < Cfg::TM; ++i)
+      for (int j = 0; j < Cfg::TN; ++j)
+        for (int v = 0; v < 4; ++v)
+          sum += acc.re[i][j][v];
+    if (sum == R(12345.678))
+      C[0] = make_el<T>(sum, 0);
+    return;
+  }
+#endif
   // ---- epilogue: C -= acc -------------------------------------------------------------------
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave % Cfg::WAVES_M, wn = wave / Cfg::WAVES_M;
   const int g = lane >> 4, c = lane & 15;
   const bool masked = !full || (diag && m0 < n0 + ncols - 1);
+  if constexpr (Cfg::PAIRED) {
+    // lane holds rows (m, m+1) of tiles (2q, 2q+1): 16-byte accesses when the tile column is aligned
+    typedef R r2 __attribute__((ext_vector_type(2)));
+    const bool wide = !masked && VEC && ((p.ldc * (long) sizeof(T)) % 16 == 0) &&
+                      (reinterpret_cast<uintptr_t>(C) % 16 == 0);
 #pragma unroll
-  for (int j = 0; j < Cfg::TN; ++j) {
+    for (int j = 0; j < Cfg::TN; ++j) {
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int nl = wn * Cfg::WN + j * 16 + Mma<R>::irow(g, v);
-      T* col = C + (long) nl * p.ldc;
-      T cv[Cfg::TM];
-      bool ok[Cfg::TM];
+      for (int v = 0; v < 4; ++v) {
+        const int nl = wn * Cfg::WN + acc_n<Cfg>(j, g, v);
+        T* col = C + (long) nl * p.ldc;
+        if (wide) {
+          r2 cv[Cfg::TM / 2];
 #pragma unroll
-      for (int i = 0; i < Cfg::TM; ++i) {
-        const int ml = wm * Cfg::WM + i * 16 + c;
-        ok[i] = !masked || (ml < mrows && nl < ncols && (!diag || (m0 + ml) >= (n0 + nl)));
-        if (ok[i])
-          cv[i] = col[ml];
-      }
+          for (int q = 0; q < Cfg::TM / 2; ++q)
+            cv[q] = *reinterpret_cast<const r2*>(col + wm * Cfg::WM + q * 32 + 2 * c);
 #pragma unroll
-      for (int i = 0; i < Cfg::TM; ++i) {
-        const int ml = wm * Cfg::WM + i * 16 + c;
-        if (ok[i]) {
-          if constexpr (Cfg::CX) {
-            T r{cv[i].re - acc.re[i][j][v], cv[i].im - acc.im[i][j][v]};
-            if (diag && (m0 + ml) == (n0 + nl))
-              r.im = R(0);
-            col[ml] = r;
+          for (int q = 0; q < Cfg::TM / 2; ++q) {
+            cv[q][0] -= acc.re[2 * q][j][v];
+            cv[q][1] -= acc.re[2 * q + 1][j][v];
+            *reinterpret_cast<r2*>(col + wm * Cfg::WM + q * 32 + 2 * c) = cv[q];
           }
-          else {
-            col[ml] = cv[i] - acc.re[i][j][v];
+        }
+        else {
+#pragma unroll
+          for (int i = 0; i < Cfg::TM; ++i) {
+            const int ml = wm * Cfg::WM + acc_m<Cfg>(i, c);
+            if (!masked || (ml < mrows && nl < ncols && (!diag || (m0 + ml) >= (n0 + nl))))
+              col[ml] = col[ml] - acc.re[i][j][v];
+          }
+        }
+      }
+    }
+  }
+  else {
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int nl = wn * Cfg::WN + acc_n<Cfg>(j, g, v);
+        T* col = C + (long) nl * p.ldc;
+        T cv[Cfg::TM];
+        bool ok[Cfg::TM];
+#pragma unroll
+        for (int i = 0; i < Cfg::TM; ++i) {
+          const int ml = wm * Cfg::WM + acc_m<Cfg>(i, c);
+          ok[i] = !masked || (ml < mrows && nl < ncols && (!diag || (m0 + ml) >= (n0 + nl)));
+          if (ok[i])
+            cv[i] = col[ml];
+        }
+#pragma unroll
+        for (int i = 0; i < Cfg::TM; ++i) {
+          const int ml = wm * Cfg::WM + acc_m<Cfg>(i, c);
+          if (ok[i]) {
+            if constexpr (Cfg::CX) {
+              T r{cv[i].re - acc.re[i][j][v], cv[i].im - acc.im[i][j][v]};
+              if (diag && (m0 + ml) == (n0 + nl))
+                r.im = R(0);
+              col[ml] = r;
+            }
+            else {
+              col[ml] = cv[i] - acc.re[i][j][v];
+            }
           }
         }
       }

@@ -7,7 +7,12 @@
 
 namespace dlaf_mi355x {
 
-template <class T, int BM_, int BN_, int WM_, int WN_, int BK_>
+// PAIRED_ (real types): MFMA tiles 2q and 2q+1 of a wave hold the even / odd rows of a 32-row group,
+// so one 16-byte LDS read feeds two fragments and the epilogue moves two consecutive rows per lane
+// (16-byte global accesses).  With it the LDS image is unpadded ([k][ROWS], column stride = 0 mod
+// 256 B is what ds_read_b128's lane groups want) and, for fp64 with 128-row slabs, a slab column is
+// exactly one 1 KiB global_load_lds_dwordx4 -- the direct-to-LDS staging of the fast path.
+template <class T, int BM_, int BN_, int WM_, int WN_, int BK_, bool PAIRED_ = false>
 struct BlockCfg {
   using R = real_t<T>;
   static constexpr bool CX = TypeInfo<T>::is_complex;
@@ -16,7 +21,12 @@ struct BlockCfg {
   static constexpr int WAVES_M = BM / WM, WAVES_N = BN / WN;
   static_assert(WAVES_M * WAVES_N * 64 == kThreads, "4 waves per workgroup");
   static_assert(BK % 4 == 0 && WM % 16 == 0 && WN % 16 == 0, "MFMA 16x16x4 granularity");
-  static constexpr int LDA = BM + kLdsPad, LDB = BN + kLdsPad;
+  static constexpr bool PAIRED = PAIRED_;
+  static_assert(!PAIRED || (!CX && TM % 2 == 0 && TN % 2 == 0), "paired rows: real types, even tile counts");
+  static constexpr int PAD = PAIRED ? 0 : kLdsPad;
+  static constexpr int LDA = BM + PAD, LDB = BN + PAD;
+  // direct-to-LDS staging: one wave instruction (64 lanes x 16 B) must be exactly one slab column
+  static constexpr bool GLDS = PAIRED && sizeof(T) * BM == 1024 && sizeof(T) * BN == 1024 && (BK % 4 == 0);
   static constexpr int A_PLANE = BK * LDA, B_PLANE = BK * LDB;
   static constexpr int A_ELEMS = (CX ? 2 : 1) * A_PLANE, B_ELEMS = (CX ? 2 : 1) * B_PLANE;
   static constexpr int BUF_ELEMS = A_ELEMS + B_ELEMS;
@@ -53,17 +63,34 @@ __device__ __forceinline__ void mma_slab(const typename Cfg::R* __restrict__ As,
   for (int k4 = 0; k4 < Cfg::BK / 4; ++k4) {
     const int kk = k4 * 4 + g;
     R a_re[Cfg::TM], a_im[Cfg::TM], b_re[Cfg::TN], b_im[Cfg::TN];
+    if constexpr (Cfg::PAIRED) {
+      typedef R r2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int i = 0; i < Cfg::TM; ++i) {
-      a_re[i] = As[kk * Cfg::LDA + wm * Cfg::WM + i * 16 + c];
-      if constexpr (Cfg::CX)
-        a_im[i] = As[Cfg::A_PLANE + kk * Cfg::LDA + wm * Cfg::WM + i * 16 + c];
+      for (int q = 0; q < Cfg::TM / 2; ++q) {
+        const r2 v = *reinterpret_cast<const r2*>(&As[kk * Cfg::LDA + wm * Cfg::WM + q * 32 + 2 * c]);
+        a_re[2 * q] = v[0];
+        a_re[2 * q + 1] = v[1];
+      }
+#pragma unroll
+      for (int q = 0; q < Cfg::TN / 2; ++q) {
+        const r2 v = *reinterpret_cast<const r2*>(&Bs[kk * Cfg::LDB + wn * Cfg::WN + q * 32 + 2 * c]);
+        b_re[2 * q] = v[0];
+        b_re[2 * q + 1] = v[1];
+      }
     }
+    else {
 #pragma unroll
-    for (int j = 0; j < Cfg::TN; ++j) {
-      b_re[j] = Bs[kk * Cfg::LDB + wn * Cfg::WN + j * 16 + c];
-      if constexpr (Cfg::CX)
-        b_im[j] = Bs[Cfg::B_PLANE + kk * Cfg::LDB + wn * Cfg::WN + j * 16 + c];
+      for (int i = 0; i < Cfg::TM; ++i) {
+        a_re[i] = As[kk * Cfg::LDA + wm * Cfg::WM + i * 16 + c];
+        if constexpr (Cfg::CX)
+          a_im[i] = As[Cfg::A_PLANE + kk * Cfg::LDA + wm * Cfg::WM + i * 16 + c];
+      }
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j) {
+        b_re[j] = Bs[kk * Cfg::LDB + wn * Cfg::WN + j * 16 + c];
+        if constexpr (Cfg::CX)
+          b_im[j] = Bs[Cfg::B_PLANE + kk * Cfg::LDB + wn * Cfg::WN + j * 16 + c];
+      }
     }
 #pragma unroll
     for (int j = 0; j < Cfg::TN; ++j)
@@ -81,6 +108,43 @@ __device__ __forceinline__ void mma_slab(const typename Cfg::R* __restrict__ As,
   }
 }
 
+// Row (m) / column (n) inside the wave tile that accumulator element (tile i or j, lane, register v)
+// stands for.  m lives on the lane's low 4 bits, n on the MFMA "i" index irow(g, v).
+template <class Cfg>
+__device__ __forceinline__ int acc_m(int i, int c) {
+  if constexpr (Cfg::PAIRED)
+    return (i >> 1) * 32 + 2 * c + (i & 1);
+  else
+    return i * 16 + c;
+}
+template <class Cfg>
+__device__ __forceinline__ int acc_n(int j, int g, int v) {
+  using R = typename Cfg::R;
+  if constexpr (Cfg::PAIRED)
+    return (j >> 1) * 32 + 2 * Mma<R>::irow(g, v) + (j & 1);
+  else
+    return j * 16 + Mma<R>::irow(g, v);
+}
+
+// Direct-to-LDS staging of one BK slab of A and B (Cfg::GLDS): wave w moves columns
+// [w*BK/4, (w+1)*BK/4) of both panels, one global_load_lds_dwordx4 (1 KiB = one column) each.
+template <class Cfg, class T>
+__device__ __forceinline__ void stage_glds(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb, int k0,
+                                           typename Cfg::R* __restrict__ buf, int wave, int lane) {
+  constexpr int PER = 16 / (int) sizeof(T);  // elements per lane
+#pragma unroll
+  for (int q = 0; q < Cfg::BK / 4; ++q) {
+    const int k = wave * (Cfg::BK / 4) + q;
+    const T* ga = A + lane * PER + (long) (k0 + k) * lda;
+    const T* gb = B + lane * PER + (long) (k0 + k) * ldb;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) ga,
+                                     (__attribute__((address_space(3))) void*) (buf + k * Cfg::LDA), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) gb,
+                                     (__attribute__((address_space(3))) void*) (buf + Cfg::A_ELEMS + k * Cfg::LDB), 16,
+                                     0, 0);
+  }
+}
+
 // acc += A(mrows x K) * B(ncols x K)^H for one BM x BN block.  lds: 2 * BUF_ELEMS of R.
 // EDGE: rows >= mrows / ncols and k >= K are zero-filled; otherwise mrows == BM, ncols == BN and
 // K % BK == 0 are the caller's promise.  All threads of the workgroup must call it.
@@ -95,8 +159,27 @@ __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda,
   const int nk = (K + Cfg::BK - 1) / Cfg::BK;
   if (nk == 0)
     return;
-  Slab<T, Cfg::BM, Cfg::BK, VEC> sa;
-  Slab<T, Cfg::BN, Cfg::BK, VEC> sb;
+  if constexpr (Cfg::GLDS && VEC && !EDGE) {
+    stage_glds<Cfg, T>(A, lda, B, ldb, 0, lds, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      R* cur = lds + (kt & 1) * Cfg::BUF_ELEMS;
+      R* nxt = lds + ((kt + 1) & 1) * Cfg::BUF_ELEMS;
+#ifdef DLAF_DBG_SKIP_GLOBAL
+      cur = lds;
+#else
+      if (kt + 1 < nk)
+        stage_glds<Cfg, T>(A, lda, B, ldb, (kt + 1) * Cfg::BK, nxt, wave, lane);
+#endif
+      mma_slab<Cfg>(cur, cur + Cfg::A_ELEMS, acc, wm, wn, lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    return;
+  }
+  Slab<T, Cfg::BM, Cfg::BK, VEC, Cfg::LDA> sa;
+  Slab<T, Cfg::BN, Cfg::BK, VEC, Cfg::LDB> sb;
   sa.template load<EDGE>(A, lda, 0, mrows, K);
   sb.template load<EDGE>(B, ldb, 0, ncols, K);
   sa.store(lds);
@@ -105,7 +188,12 @@ __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda,
   for (int kt = 0; kt < nk; ++kt) {
     R* cur = lds + (kt & 1) * Cfg::BUF_ELEMS;
     R* nxt = lds + ((kt + 1) & 1) * Cfg::BUF_ELEMS;
+#ifdef DLAF_DBG_SKIP_GLOBAL
+    const bool more = false;  // tuning aid: reuse the first slab, no global traffic in the loop
+    cur = lds;
+#else
     const bool more = (kt + 1) < nk;
+#endif
     if (more) {
       sa.template load<EDGE>(A, lda, (kt + 1) * Cfg::BK, mrows, K);
       sb.template load<EDGE>(B, ldb, (kt + 1) * Cfg::BK, ncols, K);

@@ -160,7 +160,7 @@ void DeviceMatrix<T>::create(Grid* g, char uplo_, long n_, int nb_, int isrc, in
   // the critical-path kernels (POTRF chain, panel TRSM) never queue behind long update workgroups.
   const char* serial = std::getenv("DLAF_MI355X_SERIAL");
   const char* rcu = std::getenv("DLAF_MI355X_RESERVED_CUS");
-  const int reserved = rcu ? std::atoi(rcu) : 0;
+  const int reserved = rcu ? std::atoi(rcu) : 0;  // CU-masked streams measured slower on MI355X
   if (serial && std::atoi(serial) != 0) {
     s_low = s_high;
   }
@@ -388,12 +388,20 @@ static void potrf_tile(T* t, int ld, int kb, T* winv, int* info, int info_base, 
 
 // ------------------------------------------------------------------------------- the tile DAG
 // Right-looking Cholesky (cholesky/impl.h:150-189 local, :192-313 distributed) of the lower
-// triangle of the view.  Per step k:
-//   s_high : POTRF(k,k) -> [diag tile bcast down the owning process column] -> panel TRSM
-//            -> update of tile column k+1 (the reference's high-priority lookahead column)
-//   s_comm : panel bcast along process rows, transposed-panel bcast along process columns
-//   s_low  : update of tile columns > k+1
-// Events carry the RAW/WAR edges the reference gets from per-tile async_rw_mutex.
+// triangle of the view.  Three in-order streams; events carry the RAW/WAR edges the reference gets
+// from per-tile async_rw_mutex.  Stream order on s_main for step k (U(k, J) = trailing update of
+// tile columns J with panel k):
+//
+//   s_main : U(k-1, col k) . U(k-1, rest_A) . TRSM(k) . U(k-1, rest_B) . U(k, col k+1) . U(k, rest_A) ...
+//   s_panel:                  POTRF(k)  [diag bcast]                      POTRF(k+1)
+//   s_comm :                                          panel(k) / panelT(k) broadcasts
+//
+// i.e. the narrow, latency-bound POTRF chain of the NEXT diagonal tile runs beside the first slice
+// (rest_A) of the current bulk update on compute units kept out of s_main's CU mask, the wide
+// kernels never compete with each other, and the panel broadcasts of step k fly under rest_B of step
+// k-1.  This is the reference's lookahead rule (high priority for potrf/trsm and for trailing column
+// k+1, impl.h:172-173 / :280-281) expressed as an explicit order, because on this GPU a
+// high-priority stream's kernels do not pre-empt the queued workgroups of a running bulk kernel.
 template <class T>
 void DeviceMatrix<T>::factorize_async() {
   Transport* tr = grid->transport.get();
@@ -405,15 +413,16 @@ void DeviceMatrix<T>::factorize_async() {
   // uplo == 'U' runs on the transposed view: its process rows are the caller's process columns
   const CommAxis ax_row = transposed ? CommAxis::Col : CommAxis::Row;
   const CommAxis ax_col = transposed ? CommAxis::Row : CommAxis::Col;
+  hipStream_t s_main = s_low, s_panel = s_high;
 
   for (auto& ps : prof) {
     ps.used = 0;
     ps.flops = ps.bytes = ps.ms = 0;
     ps.launches = 0;
   }
-  DLAF_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int), s_high));
-  DLAF_HIP_CHECK(hipEventRecord(ev_bcastT[0], s_high));
-  DLAF_HIP_CHECK(hipStreamWaitEvent(s_low, ev_bcastT[0], 0));
+  DLAF_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int), s_panel));
+  DLAF_HIP_CHECK(hipEventRecord(ev_bcastT[0], s_panel));
+  DLAF_HIP_CHECK(hipStreamWaitEvent(s_main, ev_bcastT[0], 0));
   DLAF_HIP_CHECK(hipStreamWaitEvent(s_comm, ev_bcastT[0], 0));
 
   // algorithmic work of one grouped update launch (BASELINE.md roofline table):
@@ -439,12 +448,21 @@ void DeviceMatrix<T>::factorize_async() {
     }
   };
 
-  auto update = [&](const T* a_base, long a_il0, const T* b_base, long b_ts, long b_jl0, long j0, long j1,
-                    int kb, hipStream_t s, int role) {
-    if (j0 >= j1)
+  // operands of step k's trailing update, kept until the update has been issued in full
+  struct Step {
+    const T* a_base = nullptr;  // column panel: tile of local row il at a_base + (il - il_n)*tile_elems
+    const T* b_base = nullptr;  // transposed panel: tile of local col jl at b_base + (jl - jl_n)*b_ts
+    long b_ts = 0, il_n = 0, jl_n = 0;
+    int kb = 0;
+    long rest0 = 0, split = 0;  // rest_A = [rest0, split), rest_B = [split, ltc)
+    bool valid = false;
+  };
+
+  auto update = [&](const Step& st, long j0, long j1, hipStream_t s, int role) {
+    if (!st.valid || j0 >= j1)
       return;
     // rows that can hold tiles on/below the diagonal of column block j0
-    const long il0 = std::max(a_il0, rows.next_local(cols.global_of(j0)));
+    const long il0 = std::max(st.il_n, rows.next_local(cols.global_of(j0)));
     if (il0 >= ltr)
       return;
     UpdateArgs<T> ua;
@@ -452,18 +470,18 @@ void DeviceMatrix<T>::factorize_async() {
     ua.c_tsr = (long) tile_elems;
     ua.c_tsc = (long) (tile_elems * ltr);
     ua.ldc = nb;
-    ua.a = a_base + (size_t) (il0 - a_il0) * tile_elems;
+    ua.a = st.a_base + (size_t) (il0 - st.il_n) * tile_elems;
     ua.a_ts = (long) tile_elems;
     ua.lda = nb;
-    ua.b = b_base + (j0 - b_jl0) * b_ts;
-    ua.b_ts = b_ts;
+    ua.b = st.b_base + (j0 - st.jl_n) * st.b_ts;
+    ua.b_ts = st.b_ts;
     ua.ldb = nb;
     ua.il0 = (int) il0;
     ua.il1 = (int) ltr;
     ua.jl0 = (int) j0;
     ua.jl1 = (int) j1;
     ua.nb = nb;
-    ua.K = kb;
+    ua.K = st.kb;
     ua.pr = rows.P;
     ua.ri = rows.shift();
     ua.pc = cols.P;
@@ -472,12 +490,21 @@ void DeviceMatrix<T>::factorize_async() {
     ua.last_rows = last_rows;
     ua.info = info;
     double fl, by;
-    update_work(il0, j0, j1, kb, fl, by);
+    update_work(il0, j0, j1, st.kb, fl, by);
     prof_begin(role, s);
     launch_update(ua, s, role);
     prof_end(role, s, fl, by);
   };
 
+  // rest_A must last about as long as the POTRF chain of the next diagonal tile
+  // (~ (nb/64) dependent sub-steps of ~90 us) at the bulk update's rate
+  const double lookahead_flops = [&] {
+    if (const char* e = std::getenv("DLAF_MI355X_LOOKAHEAD_FLOPS"))
+      return std::atof(e);
+    return 90e-6 * ((double) nb / kDiagBlock) * 55e12;
+  }();
+
+  Step prev;  // step k-1, whose rest_B is still to be issued
   for (long k = 0; k < nt; ++k) {
     const int kb = rows.tile_extent(k);
     const int own_r = rows.owner(k), own_c = cols.owner(k);
@@ -486,91 +513,100 @@ void DeviceMatrix<T>::factorize_async() {
     const int buf = (int) (k & 1);
     const long klc = in_col ? cols.local_of(k) : -1;
 
-    // ---- diagonal tile ---------------------------------------------------------------------------
+    // ---- s_panel: diagonal tile (column k is final once U(k-1, col k) has run: ev_high[k-1]) ---------
     const T* Lkk = nullptr;
     const T* Wkk = nullptr;
+    if (k >= 1)
+      DLAF_HIP_CHECK(hipStreamWaitEvent(s_panel, ev_high[k - 1], 0));
     if (in_row && in_col) {
       T* tkk = tile(rows.local_of(k), klc);
       const double cxf = TypeInfo<T>::is_complex ? 4.0 : 1.0;
-      prof_begin(3, s_high);
-      potrf_tile(tkk, nb, kb, winv, info, (int) (k * nb), s_high);
-      prof_end(3, s_high, cxf * (double) kb * kb * kb / 3.0, (double) kb * kb * sizeof(T));
+      prof_begin(3, s_panel);
+      potrf_tile(tkk, nb, kb, winv, info, (int) (k * nb), s_panel);
+      prof_end(3, s_panel, cxf * (double) kb * kb * kb / 3.0, (double) kb * kb * sizeof(T));
       Lkk = tkk;
       Wkk = winv;
     }
-    if (k == nt - 1)
+    if (k == nt - 1) {
+      // nothing trails the last diagonal tile; flush what is left of step k-1
+      update(prev, prev.rest0, prev.split, s_main, 0);
+      update(prev, prev.split, ltc, s_main, 0);
+      prev.valid = false;
+      DLAF_HIP_CHECK(hipEventRecord(ev_diag[k], s_panel));
+      DLAF_HIP_CHECK(hipStreamWaitEvent(s_main, ev_diag[k], 0));
       break;
-
-    // ---- diag tile down the owning process column, then the panel TRSM -------------------------
-    if (in_col) {
-      if (rows.P > 1) {
-        if (in_row) {
-          DLAF_HIP_CHECK(hipMemcpyAsync(diag_ws, Lkk, tile_bytes, hipMemcpyDeviceToDevice, s_high));
-          DLAF_HIP_CHECK(hipMemcpyAsync(diag_ws + tile_elems, Wkk, winv_elems() * sizeof(T),
-                                        hipMemcpyDeviceToDevice, s_high));
-        }
-        // s_high is past the previous step's TRSM (last reader of diag_ws) at this point
-        DLAF_HIP_CHECK(hipEventRecord(ev_diag[k], s_high));
-        DLAF_HIP_CHECK(hipStreamWaitEvent(s_comm, ev_diag[k], 0));
-        tr->bcast(ax_col, own_r, rows.rank, diag_ws, diag_ws, tile_bytes + winv_elems() * sizeof(T), s_comm);
-        DLAF_HIP_CHECK(hipEventRecord(ev_diag[k], s_comm));
-        DLAF_HIP_CHECK(hipStreamWaitEvent(s_high, ev_diag[k], 0));
-        Lkk = diag_ws;
-        Wkk = diag_ws + tile_elems;
-      }
-      if (il_n < ltr) {
-        TrsmArgs<T> ta;
-        ta.b = tile(il_n, klc);
-        ta.b_ts = (long) tile_elems;
-        ta.ldb = nb;
-        ta.il0 = (int) il_n;
-        ta.il1 = (int) ltr;
-        ta.pr = rows.P;
-        ta.ri = rows.shift();
-        ta.nb = nb;
-        ta.nt = (int) nt;
-        ta.last_rows = last_rows;
-        ta.l = Lkk;
-        ta.ldl = nb;
-        ta.winv = Wkk;
-        ta.n = kb;
-        ta.info = info;
-        // algorithmic work: n^2 m flop and (n^2/2 + 2 m n) elements per tile
-        double fl = 0, by = 0;
-        for (long il = il_n; il < ltr; ++il) {
-          const double mi = rows.tile_extent(rows.global_of(il));
-          fl += (TypeInfo<T>::is_complex ? 4.0 : 1.0) * (double) kb * kb * mi;
-          by += (0.5 * kb * kb + 2.0 * mi * kb) * sizeof(T);
-        }
-        prof_begin(2, s_high);
-        launch_trsm(ta, s_high);
-        prof_end(2, s_high, fl, by);
-      }
     }
-    DLAF_HIP_CHECK(hipEventRecord(ev_panel[k], s_high));
-
-    // ---- panel along process rows, transposed panel along process columns ---------------------
-    const T* a_base = nullptr;  // column panel: tile of local row il at a_base + (il - il_n)*tile_elems
-    const T* b_base = nullptr;  // transposed panel: tile of local col jl at b_base + (jl - jl_n)*b_ts
-    long b_ts = (long) tile_elems;
-    bool comm_used = false;
-    if (dist) {
-      DLAF_HIP_CHECK(hipStreamWaitEvent(s_comm, ev_panel[k], 0));
-      if (k >= 2) {  // the workspaces of step k-2 are about to be overwritten
-        DLAF_HIP_CHECK(hipStreamWaitEvent(s_comm, ev_low[k - 2], 0));
-        DLAF_HIP_CHECK(hipStreamWaitEvent(s_comm, ev_high[k - 2], 0));
+    if (in_col && rows.P > 1) {
+      // diag tile (+ its inverted diagonal blocks) down the owning process column
+      if (in_row) {
+        DLAF_HIP_CHECK(hipMemcpyAsync(diag_ws, Lkk, tile_bytes, hipMemcpyDeviceToDevice, s_panel));
+        DLAF_HIP_CHECK(hipMemcpyAsync(diag_ws + tile_elems, Wkk, winv_elems() * sizeof(T), hipMemcpyDeviceToDevice,
+                                      s_panel));
       }
-    }
-    if (cols.P > 1) {
-      T* dst = in_col ? tile(il_n < ltr ? il_n : 0, klc) : panel[buf];
-      if (il_n < ltr) {
-        tr->bcast(ax_row, own_c, cols.rank, dst, dst, (size_t) (ltr - il_n) * tile_bytes, s_comm);
-        comm_used = true;
-      }
-      a_base = dst;
+      DLAF_HIP_CHECK(hipEventRecord(ev_diag[k], s_panel));
+      DLAF_HIP_CHECK(hipStreamWaitEvent(s_comm, ev_diag[k], 0));
+      tr->bcast(ax_col, own_r, rows.rank, diag_ws, diag_ws, tile_bytes + winv_elems() * sizeof(T), s_comm);
+      DLAF_HIP_CHECK(hipEventRecord(ev_diag[k], s_comm));
+      Lkk = diag_ws;
+      Wkk = diag_ws + tile_elems;
     }
     else {
-      a_base = tile(il_n < ltr ? il_n : 0, klc);
+      DLAF_HIP_CHECK(hipEventRecord(ev_diag[k], s_panel));
+    }
+
+    // ---- s_main: first slice of the previous step's bulk update runs beside the POTRF chain -----------
+    update(prev, prev.rest0, prev.split, s_main, 0);
+
+    // ---- s_main: panel TRSM ------------------------------------------------------------------------------
+    DLAF_HIP_CHECK(hipStreamWaitEvent(s_main, ev_diag[k], 0));
+    if (in_col && il_n < ltr) {
+      TrsmArgs<T> ta;
+      ta.b = tile(il_n, klc);
+      ta.b_ts = (long) tile_elems;
+      ta.ldb = nb;
+      ta.il0 = (int) il_n;
+      ta.il1 = (int) ltr;
+      ta.pr = rows.P;
+      ta.ri = rows.shift();
+      ta.nb = nb;
+      ta.nt = (int) nt;
+      ta.last_rows = last_rows;
+      ta.l = Lkk;
+      ta.ldl = nb;
+      ta.winv = Wkk;
+      ta.n = kb;
+      ta.info = info;
+      // algorithmic work: n^2 m flop and (n^2/2 + 2 m n) elements per tile
+      double fl = 0, by = 0;
+      for (long il = il_n; il < ltr; ++il) {
+        const double mi = rows.tile_extent(rows.global_of(il));
+        fl += (TypeInfo<T>::is_complex ? 4.0 : 1.0) * (double) kb * kb * mi;
+        by += (0.5 * kb * kb + 2.0 * mi * kb) * sizeof(T);
+      }
+      prof_begin(2, s_main);
+      launch_trsm(ta, s_main);
+      prof_end(2, s_main, fl, by);
+    }
+    DLAF_HIP_CHECK(hipEventRecord(ev_panel[k], s_main));
+
+    // ---- s_comm: panel along process rows, transposed panel along process columns --------------------
+    Step cur;
+    cur.valid = true;
+    cur.kb = kb;
+    cur.il_n = il_n;
+    cur.jl_n = jl_n;
+    cur.b_ts = (long) tile_elems;
+    if (dist)
+      DLAF_HIP_CHECK(hipStreamWaitEvent(s_comm, ev_panel[k], 0));
+    if (cols.P > 1) {
+      // the workspace of step k-2 is free: its readers are behind TRSM(k) on s_main (ev_panel[k])
+      T* dst = in_col ? tile(il_n < ltr ? il_n : 0, klc) : panel[buf];
+      if (il_n < ltr)
+        tr->bcast(ax_row, own_c, cols.rank, dst, dst, (size_t) (ltr - il_n) * tile_bytes, s_comm);
+      cur.a_base = dst;
+    }
+    else {
+      cur.a_base = tile(il_n < ltr ? il_n : 0, klc);
     }
     if (rows.P > 1) {
       tr->group_begin();
@@ -579,40 +615,47 @@ void DeviceMatrix<T>::factorize_async() {
         if (gj == nt - 1)
           continue;  // last tile row is only ever a herk operand (broadcast_panel.h:186-191)
         const int root_r = rows.owner(gj);
-        const T* src = (rows.rank == root_r) ? a_base + (size_t) (rows.local_of(gj) - il_n) * tile_elems : nullptr;
-        tr->bcast(ax_col, root_r, rows.rank, src, panelT[buf] + (size_t) (jl - jl_n) * tile_elems, tile_bytes,
-                  s_comm);
-        comm_used = true;
+        const T* src = (rows.rank == root_r) ? cur.a_base + (size_t) (rows.local_of(gj) - il_n) * tile_elems : nullptr;
+        tr->bcast(ax_col, root_r, rows.rank, src, panelT[buf] + (size_t) (jl - jl_n) * tile_elems, tile_bytes, s_comm);
       }
       tr->group_end();
-      b_base = panelT[buf];
+      cur.b_base = panelT[buf];
     }
     else {
       // I hold every row of the panel: tile gj sits at local row gj
-      b_base = a_base + (cols.global_of(jl_n) - il_n) * (long) tile_elems;
-      b_ts = (long) tile_elems * cols.P;
+      cur.b_base = cur.a_base + (cols.global_of(jl_n) - il_n) * (long) tile_elems;
+      cur.b_ts = (long) tile_elems * cols.P;
     }
-    if (dist) {
+    if (dist)
       DLAF_HIP_CHECK(hipEventRecord(ev_bcast[k], s_comm));
-      DLAF_HIP_CHECK(hipStreamWaitEvent(s_high, ev_bcast[k], 0));
-      DLAF_HIP_CHECK(hipStreamWaitEvent(s_low, ev_bcast[k], 0));
-    }
-    (void) comm_used;
 
-    // ---- trailing update: lookahead column on s_high, the rest on s_low --------------------------
-    if (k >= 1)
-      DLAF_HIP_CHECK(hipStreamWaitEvent(s_high, ev_low[k - 1], 0));
-    long rest0 = jl_n;
+    // ---- s_main: rest of step k-1 (the broadcasts of step k fly underneath) ---------------------------
+    update(prev, prev.split, ltc, s_main, 0);
+    if (dist)
+      DLAF_HIP_CHECK(hipStreamWaitEvent(s_main, ev_bcast[k], 0));
+
+    // ---- s_main: lookahead column of step k, then split the rest ------------------------------------
+    cur.rest0 = jl_n;
     if (cols.mine(k + 1) && jl_n < ltc) {
-      update(a_base, il_n, b_base, b_ts, jl_n, jl_n, jl_n + 1, kb, s_high, 1);
-      rest0 = jl_n + 1;
+      update(cur, jl_n, jl_n + 1, s_main, 1);
+      cur.rest0 = jl_n + 1;
     }
-    DLAF_HIP_CHECK(hipEventRecord(ev_high[k], s_high));
-    DLAF_HIP_CHECK(hipStreamWaitEvent(s_low, ev_panel[k], 0));
-    update(a_base, il_n, b_base, b_ts, jl_n, rest0, ltc, kb, s_low, 0);
-    DLAF_HIP_CHECK(hipEventRecord(ev_low[k], s_low));
+    DLAF_HIP_CHECK(hipEventRecord(ev_high[k], s_main));
+    cur.split = cur.rest0;
+    {
+      double acc = 0;
+      while (cur.split < ltc && acc < lookahead_flops) {
+        double fl, by;
+        update_work(std::max(il_n, rows.next_local(cols.global_of(cur.split))), cur.split, cur.split + 1, kb, fl, by);
+        acc += fl;
+        ++cur.split;
+      }
+    }
+    prev = cur;
   }
-  DLAF_HIP_CHECK(hipMemcpyAsync(info_host, info, sizeof(int), hipMemcpyDeviceToHost, s_high));
+  DLAF_HIP_CHECK(hipEventRecord(ev_low[0], s_main));
+  DLAF_HIP_CHECK(hipStreamWaitEvent(s_panel, ev_low[0], 0));
+  DLAF_HIP_CHECK(hipMemcpyAsync(info_host, info, sizeof(int), hipMemcpyDeviceToHost, s_panel));
 }
 
 template <class T>

@@ -1,0 +1,67 @@
+// update_bench.hip -- standalone timing of the grouped trailing-update kernel on a synthetic
+// local matrix (one launch over all tiles below the first tile column), for kernel tuning.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include tools/update_bench.hip -o /tmp/update_bench
+//   /tmp/update_bench [nt=24] [nb=1024] [reps=3]
+// Debug variants (compile-time): -DDLAF_DBG_SKIP_EPILOGUE  -DDLAF_DBG_SKIP_GLOBAL
+#include "../dla_future_amd/csrc/device/kernels_update.hip"
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+using namespace dlaf_mi355x;
+
+int main(int argc, char** argv) {
+  const int nt = argc > 1 ? atoi(argv[1]) : 24;
+  const int nb = argc > 2 ? atoi(argv[2]) : 1024;
+  const int reps = argc > 3 ? atoi(argv[3]) : 3;
+  update_kernels_init();
+  const size_t te = (size_t) nb * nb;
+  double* tiles;
+  int* info;
+  (void) hipMalloc(&tiles, sizeof(double) * te * nt * nt);
+  (void) hipMalloc(&info, sizeof(int));
+  (void) hipMemset(info, 0, sizeof(int));
+  std::vector<double> h(te * nt);
+  srand(1);
+  for (auto& v : h) v = (rand() / (double) RAND_MAX) * 2 - 1;
+  for (int j = 0; j < nt; ++j)
+    (void) hipMemcpy(tiles + te * nt * j, h.data(), sizeof(double) * te * nt, hipMemcpyHostToDevice);
+  UpdateArgs<double> ua;
+  ua.c = tiles;
+  ua.c_tsr = (long) te;
+  ua.c_tsc = (long) te * nt;
+  ua.ldc = nb;
+  ua.a = tiles + te;  // column 0, rows 1..
+  ua.a_ts = (long) te;
+  ua.lda = nb;
+  ua.b = tiles + te;
+  ua.b_ts = (long) te;
+  ua.ldb = nb;
+  ua.il0 = ua.jl0 = 1;
+  ua.il1 = ua.jl1 = nt;
+  ua.nb = nb;
+  ua.K = nb;
+  ua.pr = ua.pc = 1;
+  ua.ri = ua.ci = 0;
+  ua.nt = nt;
+  ua.last_rows = nb;
+  ua.info = info;
+  const double t = nt - 1;
+  const double flops = t * (t - 1) / 2 * 2.0 * nb * nb * nb + t * (double) nb * (nb + 1) * nb;
+  hipEvent_t e0, e1;
+  (void) hipEventCreate(&e0);
+  (void) hipEventCreate(&e1);
+  launch_update(ua, nullptr, 0);
+  (void) hipDeviceSynchronize();
+  for (int r = 0; r < reps; ++r) {
+    (void) hipEventRecord(e0);
+    launch_update(ua, nullptr, 0);
+    (void) hipEventRecord(e1);
+    (void) hipDeviceSynchronize();
+    float ms;
+    (void) hipEventElapsedTime(&ms, e0, e1);
+    printf("nt=%d nb=%d: %.3f ms  %.2f TFlop/s\n", nt, nb, ms, flops / ms / 1e9);
+  }
+  return 0;
+}
