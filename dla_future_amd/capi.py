@@ -63,6 +63,7 @@ SIGNATURES = {
     "dlaf_mi355x_rccl_unique_id": (None, [_vp]),
     "dlaf_mi355x_create_grid_rccl": (_i, [_vp, _i, _i, _i, _i, _ch]),
     "dlaf_mi355x_create_grid_host": (_i, [_i, _i, _i, _i, _ch, BCAST_FN, BARRIER_FN, _vp]),
+    "dlaf_mi355x_grid_host_bcast": (_i, [_i, _i, _i, _vp, C.c_size_t]),
     "dlaf_mi355x_grid_info": (_i, [_i, _IP, _IP, _IP, _IP]),
     "dlaf_mi355x_grid_barrier": (_i, [_i]),
     "dlaf_mi355x_matrix_create": (_i, [_i, _ch, _ch, DLAFDescriptor, C.POINTER(_vp)]),
@@ -97,6 +98,14 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own libamdhip64 / librccl (same SONAMEs as /opt/rocm's).  Two copies in one
+    # process abort at exit, so when torch is installed it must be loaded FIRST: our library then binds
+    # to the runtime torch brought in.  DLAF_MI355X_NO_TORCH=1 skips this (pure C / numpy users).
+    if os.environ.get("DLAF_MI355X_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     path = lib_path()
     if not os.path.exists(path):
         raise LibraryNotBuilt(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "

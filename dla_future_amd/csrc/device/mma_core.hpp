@@ -12,7 +12,10 @@ namespace dlaf_mi355x {
 // (16-byte global accesses).  With it the LDS image is unpadded ([k][ROWS], column stride = 0 mod
 // 256 B is what ds_read_b128's lane groups want) and, for fp64 with 128-row slabs, a slab column is
 // exactly one 1 KiB global_load_lds_dwordx4 -- the direct-to-LDS staging of the fast path.
-template <class T, int BM_, int BN_, int WM_, int WN_, int BK_, bool PAIRED_ = false>
+// STAGES_: LDS slab buffers.  2 = classic double buffering; the direct-to-LDS path uses more so that
+// STAGES-1 slabs are in flight (counted s_waitcnt vmcnt + raw s_barrier) and HBM/L2 latency spikes
+// do not stall the MFMA stream.
+template <class T, int BM_, int BN_, int WM_, int WN_, int BK_, bool PAIRED_ = false, int STAGES_ = 2>
 struct BlockCfg {
   using R = real_t<T>;
   static constexpr bool CX = TypeInfo<T>::is_complex;
@@ -30,7 +33,9 @@ struct BlockCfg {
   static constexpr int A_PLANE = BK * LDA, B_PLANE = BK * LDB;
   static constexpr int A_ELEMS = (CX ? 2 : 1) * A_PLANE, B_ELEMS = (CX ? 2 : 1) * B_PLANE;
   static constexpr int BUF_ELEMS = A_ELEMS + B_ELEMS;
-  static constexpr int LDS_BYTES = 2 * BUF_ELEMS * (int) sizeof(R);
+  static constexpr int STAGES = STAGES_;
+  static_assert(STAGES >= 2 && STAGES <= 4, "2..4 LDS stages");
+  static constexpr int LDS_BYTES = STAGES * BUF_ELEMS * (int) sizeof(R);
 };
 
 template <class Cfg>
@@ -160,21 +165,41 @@ __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda,
   if (nk == 0)
     return;
   if constexpr (Cfg::GLDS && VEC && !EDGE) {
-    stage_glds<Cfg, T>(A, lda, B, ldb, 0, lds, wave, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // multi-stage direct-to-LDS pipeline: slabs kt+1 .. kt+STAGES-1 are in flight while slab kt is
+    // consumed.  Each wave issues LPS loads per slab; "vmcnt(LPS*(STAGES-2))" therefore means "my share
+    // of slab kt+1 has landed", and the raw barrier extends that to every wave's share.
+    constexpr int ST = Cfg::STAGES;
+    constexpr int LPS = 2 * (Cfg::BK / 4);
+#pragma unroll
+    for (int s = 0; s < ST - 1; ++s)
+      if (s < nk)
+        stage_glds<Cfg, T>(A, lda, B, ldb, s * Cfg::BK, lds + s * Cfg::BUF_ELEMS, wave, lane);
+    // slab 0 must be complete: everything but the younger (ST-2) slabs
+    if (nk >= ST - 1)
+      __builtin_amdgcn_s_waitcnt(0x0070 | ((LPS * (ST - 2)) & 0xF) | ((((LPS * (ST - 2)) >> 4) & 0x3) << 14));
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int cur_i = 0, nxt_i = ST - 1;
     for (int kt = 0; kt < nk; ++kt) {
-      R* cur = lds + (kt & 1) * Cfg::BUF_ELEMS;
-      R* nxt = lds + ((kt + 1) & 1) * Cfg::BUF_ELEMS;
+      R* cur = lds + cur_i * Cfg::BUF_ELEMS;
 #ifdef DLAF_DBG_SKIP_GLOBAL
       cur = lds;
 #else
-      if (kt + 1 < nk)
-        stage_glds<Cfg, T>(A, lda, B, ldb, (kt + 1) * Cfg::BK, nxt, wave, lane);
+      if (kt + ST - 1 < nk)
+        stage_glds<Cfg, T>(A, lda, B, ldb, (kt + ST - 1) * Cfg::BK, lds + nxt_i * Cfg::BUF_ELEMS, wave, lane);
 #endif
       mma_slab<Cfg>(cur, cur + Cfg::A_ELEMS, acc, wm, wn, lane);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      // next slab (kt+1) landed?  loads still allowed in flight: those of slabs kt+2 .. kt+ST-1
+      const int younger = min(ST - 2, max(0, nk - 2 - kt));
+      if (younger == ST - 2)
+        __builtin_amdgcn_s_waitcnt(0x0070 | ((LPS * (ST - 2)) & 0xF) | ((((LPS * (ST - 2)) >> 4) & 0x3) << 14));
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      cur_i = (cur_i + 1 == ST) ? 0 : cur_i + 1;
+      nxt_i = (nxt_i + 1 == ST) ? 0 : nxt_i + 1;
     }
     return;
   }

@@ -241,8 +241,12 @@ int dlaf_mi355x_create_grid_host(int nranks, int rank, int nprow, int npcol, cha
   auto g = make_grid(nranks, rank, nprow, npcol, order);
   if (!g || (nranks > 1 && !bcast))
     return -1;
-  if (nranks > 1)
-    g->transport = make_host_transport(bcast, barrier, user);
+  if (nranks > 1) {
+    g->host_bcast = bcast;
+    g->host_user = user;
+    g->host_barrier = barrier;
+    // the transport itself (pinned staging buffer, HIP) is created on first use by a matrix
+  }
   return register_grid(std::move(g));
 }
 
@@ -262,11 +266,26 @@ int dlaf_mi355x_grid_barrier(int ctx) noexcept {
   auto it = g_grids.find(ctx);
   if (it == g_grids.end())
     return -1;
-  if (it->second->transport)
-    it->second->transport->barrier(nullptr);
-  else
+  Grid& g = *it->second;
+  if (g.transport)
+    g.transport->barrier(nullptr);
+  else if (g.host_barrier)
+    return g.host_barrier(g.host_user);
+  else if (runtime_initialized())
     (void) hipDeviceSynchronize();
   return 0;
+}
+
+int dlaf_mi355x_grid_host_bcast(int ctx, int axis, int root, void* host_buf, size_t bytes) noexcept {
+  // exercises the grid's broadcast callback with a caller-owned HOST buffer (no GPU involved):
+  // lets CPU-only multi-process tests check the row/column communicator wiring of a host grid
+  auto it = g_grids.find(ctx);
+  if (it == g_grids.end() || (axis != 0 && axis != 1))
+    return -1;
+  Grid& g = *it->second;
+  if (!g.host_bcast)
+    return g.nranks == 1 ? 0 : -2;
+  return g.host_bcast(g.host_user, axis, root, host_buf, bytes);
 }
 
 int dlaf_mi355x_matrix_create(int ctx, char type, char uplo, DLAF_descriptor d, dlaf_mi355x_matrix_t* out) noexcept {

@@ -122,6 +122,8 @@ void DeviceMatrix<T>::create(Grid* g, char uplo_, long n_, int nb_, int isrc, in
   runtime_init();
   type = TypeInfo<T>::tag;
   grid = g;
+  if (g->nranks > 1 && !g->transport && g->host_bcast)
+    g->transport = make_host_transport(g->host_bcast, g->host_barrier, g->host_user);
   uplo = (uplo_ == 'U' || uplo_ == 'u') ? 'U' : 'L';
   transposed = (uplo == 'U');
   n = n_;

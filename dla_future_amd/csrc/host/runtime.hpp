@@ -57,7 +57,10 @@ struct Grid {
   int myrow = 0, mycol = 0;
   int rank = 0, nranks = 1;
   char order = 'R';
-  std::unique_ptr<Transport> transport;  // null for a 1x1 grid
+  std::unique_ptr<Transport> transport;  // null for a 1x1 grid (host grids: created lazily)
+  dlaf_host_bcast_fn host_bcast = nullptr;
+  dlaf_host_barrier_fn host_barrier = nullptr;
+  void* host_user = nullptr;
 };
 
 std::unique_ptr<Transport> make_rccl_transport(const void* unique_id, int nranks, int rank, int nprow,

@@ -40,6 +40,10 @@ DLAF_EXTERN_C int dlaf_mi355x_create_grid_host(int nranks, int rank, int nprow, 
                                                dlaf_mi355x_bcast_fn bcast, dlaf_mi355x_barrier_fn barrier,
                                                void* user) DLAF_NOEXCEPT;
 
+/* Runs the grid's broadcast callback on a caller-owned HOST buffer (no GPU work): a wiring check of
+ * the row (axis 0) / column (axis 1) communicators of a host grid for CPU-only tests. */
+DLAF_EXTERN_C int dlaf_mi355x_grid_host_bcast(int context, int axis, int root, void* host_buf, size_t bytes) DLAF_NOEXCEPT;
+
 /* my coordinates in a grid; returns 0, or -1 for an unknown context */
 DLAF_EXTERN_C int dlaf_mi355x_grid_info(int context, int* nprow, int* npcol, int* myrow, int* mycol) DLAF_NOEXCEPT;
 

@@ -1,0 +1,133 @@
+"""Worker of the multi-process tests (launched with torch.distributed.run, backend gloo).
+
+mode "cpu": no GPU -- grid wiring over gloo sub-groups, block-cyclic generation, host broadcast
+            callback through the C ABI (dlaf_mi355x_grid_host_bcast).
+mode "gpu": every rank drives the SAME GPU (cuda:0) through the real distributed executor with the
+            host-staged transport over gloo and is checked against the oracle.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def make_grid(dlaf, nprow, npcol, order):
+    rank, world = dist.get_rank(), dist.get_world_size()
+
+    def coords(r):
+        return (r % nprow, r // nprow) if order == "C" else (r // npcol, r % npcol)
+
+    def rank_of(row, col):
+        return col * nprow + row if order == "C" else row * npcol + col
+
+    myrow, mycol = coords(rank)
+    # every process creates every group, in the same order (torch.distributed requirement)
+    row_groups = [dist.new_group([rank_of(r, c) for c in range(npcol)]) for r in range(nprow)]
+    col_groups = [dist.new_group([rank_of(r, c) for r in range(nprow)]) for c in range(npcol)]
+
+    def bcast(axis, root, buf):
+        t = torch.frombuffer(buf, dtype=torch.uint8)
+        if axis == 0:
+            dist.broadcast(t, src=rank_of(myrow, root), group=row_groups[myrow])
+        else:
+            dist.broadcast(t, src=rank_of(root, mycol), group=col_groups[mycol])
+
+    g = dlaf.Grid.host(world, rank, nprow, npcol, order, bcast, dist.barrier)
+    assert (g.myrow, g.mycol) == (myrow, mycol)
+    return g, rank_of
+
+
+def gather_global(loc, grid, n, nb, sr, sc, oracle):
+    """all ranks -> rank 0: the global matrix assembled from the local parts"""
+    world = dist.get_world_size()
+    parts = [None] * world
+    dist.all_gather_object(parts, (grid.myrow, grid.mycol, np.ascontiguousarray(loc)))
+    locs = {(r, c): np.asfortranarray(a) for r, c, a in parts}
+    return oracle.gather(locs, n, nb, grid.nprow, grid.npcol, sr, sc, dtype=loc.dtype)
+
+
+def main():
+    mode, nprow, npcol, order = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    dist.init_process_group("gloo")
+    import dla_future_amd as dlaf
+    from oracle import oracle
+
+    grid, rank_of = make_grid(dlaf, nprow, npcol, order)
+    rank = dist.get_rank()
+    ok = True
+    if mode == "cpu":
+        # 1. broadcast callback wiring through the C ABI: row then column communicator
+        for axis, nroots in ((0, npcol), (1, nprow)):
+            for root in range(nroots):
+                buf = np.full(37, -1, dtype=np.int64)
+                me = grid.mycol if axis == 0 else grid.myrow
+                if me == root:
+                    buf[:] = 1000 * axis + 100 * root + (grid.myrow if axis == 0 else grid.mycol)
+                r = dlaf.lib().dlaf_mi355x_grid_host_bcast(grid.context, axis, root, buf.ctypes.data, buf.nbytes)
+                assert r == 0
+                expect = 1000 * axis + 100 * root + (grid.myrow if axis == 0 else grid.mycol)
+                ok &= bool((buf == expect).all())
+        # 2. every rank generates its block-cyclic share; the assembled matrix is the oracle's
+        for (n, nb, sr, sc) in [(45, 8, 0, 0), (34, 13, nprow - 1, min(1, npcol - 1))]:
+            rows, cols = grid.local_shape(n, nb, sr, sc)
+            loc = np.zeros((max(1, rows), max(1, cols)), order="F")[:rows, :cols]
+            dlaf.set_random_hermitian_positive_definite(grid, loc, n, nb, sr, sc)
+            full = gather_global(loc, grid, n, nb, sr, sc, oracle)
+            ok &= bool(np.array_equal(full, oracle.set_random_hpd(n, nb, np.float64)))
+        grid.barrier()
+    else:
+        dlaf.initialize()
+        cases = [("d", "L", 150, 32), ("d", "U", 150, 32), ("z", "L", 100, 16), ("z", "U", 70, 16),
+                 ("s", "L", 96, 32), ("c", "U", 64, 16), ("d", "L", 34, 13), ("d", "L", 5, 8), ("d", "U", 260, 64)]
+        for t, uplo, n, nb in cases:
+            dt = oracle.DTYPES[t]
+            sr, sc = max(0, nprow - 1), min(1, npcol - 1)  # test_cholesky.cpp:85: non-zero source rank
+            rows, cols = grid.local_shape(n, nb, sr, sc)
+            store = np.full((max(1, rows) + 2, max(1, cols)), 7.5, dtype=dt, order="F")
+            loc = store[:rows, :cols]
+            dlaf.set_random_hermitian_positive_definite(grid, loc, n, nb, sr, sc)
+            a0 = gather_global(loc, grid, n, nb, sr, sc, oracle)
+            info = dlaf.cholesky_factorization(grid, uplo, loc, nb, sr, sc, n=n)
+            ok &= info == 0
+            got = gather_global(loc, grid, n, nb, sr, sc, oracle)
+            if rank == 0:
+                ref = a0.copy(order="F")
+                assert oracle.cholesky_local(uplo, ref, nb) == 0
+                err = (8 if t in "cz" else 2) * oracle.eps_of(dt)
+                tol = 4 * (n + 1) * err
+                good, md = oracle.check_near(oracle.tri(uplo, ref), oracle.tri(uplo, got), tol, tol)
+                other = np.triu(got, 1) if uplo == "L" else np.tril(got, -1)
+                other0 = np.triu(a0, 1) if uplo == "L" else np.tril(a0, -1)
+                good &= bool(np.array_equal(other, other0))
+                if not good:
+                    print(f"[dist_worker] FAILED case {t}{uplo} n={n} nb={nb} grid {nprow}x{npcol}: max diff {md}", flush=True)
+                ok &= good
+            ok &= bool((store[rows:, :] == 7.5).all())
+        # analytic known-answer matrix through the ScaLAPACK-style entry (test_cholesky_c_api.cpp:108-155)
+        n, nb = 34, 13
+        a, l = oracle.cholesky_setters("L", n, np.float64)
+        locs = oracle.scatter(a, nb, nprow, npcol, 0, 0)
+        loc = np.asfortranarray(locs[(grid.myrow, grid.mycol)])
+        lld = max(1, loc.shape[0])
+        info = dlaf.pxpotrf("L", n, loc, 1, 1, [1, grid.context, n, n, nb, nb, 0, 0, lld])
+        ok &= info == 0
+        got = gather_global(loc, grid, n, nb, 0, 0, oracle)
+        tol = 4 * (n + 1) * 2 * np.finfo(np.float64).eps
+        good, md = oracle.check_near(l, got, tol, tol)
+        ok &= good
+        grid.barrier()
+    flags = [None] * dist.get_world_size()
+    dist.all_gather_object(flags, bool(ok))
+    if rank == 0:
+        print("DIST_WORKER_RESULT", "OK" if all(flags) else f"FAIL {flags}", flush=True)
+    dist.destroy_process_group()
+    sys.exit(0 if all(flags) else 1)
+
+
+if __name__ == "__main__":
+    main()
