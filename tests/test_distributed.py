@@ -25,14 +25,28 @@ def free_port():
 
 
 def launch(mode, nprow, npcol, order, timeout):
+    """Start one worker process per rank directly (no launcher process: the GPU box allows at most 6
+    processes on the card, and 3x2 / 2x3 grids need all of them)."""
     n = nprow * npcol
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
-           "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), mode,
-           str(nprow), str(npcol), order]
-    env = dict(os.environ, OMP_NUM_THREADS="1", DLAF_MI355X_DEVICE="0")
-    env.pop("LOCAL_RANK", None)
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
-    assert r.returncode == 0 and "DIST_WORKER_RESULT OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+    port = str(free_port())
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, OMP_NUM_THREADS="1", DLAF_MI355X_DEVICE="0", RANK=str(rank), WORLD_SIZE=str(n),
+                   LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), mode, str(nprow),
+                                       str(npcol), order], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=timeout))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()  # exact PIDs we started
+    rc = [p.returncode for p in procs]
+    assert all(r == 0 for r in rc) and "DIST_WORKER_RESULT OK" in outs[0][0], \
+        (rc, outs[0][0][-2000:], "\n".join(o[1][-1500:] for o in outs))
 
 
 @pytest.mark.parametrize("nprow,npcol,order", [(1, 2, "R"), (2, 1, "C"), (2, 2, "C")])
