@@ -38,8 +38,14 @@ struct UpdateArgs {
   const int* info;  // device flag: non-zero => a previous POTRF failed, kernels return at once
 };
 // role: 0 trailing bulk, 1 lookahead column, 2 in-tile POTRF update (same code, separate kernel names)
+// max_blocks > 0 (with counters = 8 device words of scratch): launch at most that many workgroups and
+// let them pull work items (persistent form): what is left of the GPU stays free for kernels that
+// must run beside the update.
 template <class T>
-void launch_update(const UpdateArgs<T>& args, hipStream_t stream, int role = 0);
+void launch_update(const UpdateArgs<T>& args, hipStream_t stream, int role = 0, long max_blocks = 0,
+                   unsigned* counters = nullptr);
+template <class T>
+int update_blocks_per_cu();
 
 // ------------------------------------------------------------------------------------------
 // Panel TRSM (tile::trsm Right/Lower/ConjTrans/NonUnit of a whole panel in ONE launch,
@@ -72,6 +78,13 @@ void launch_trsm(const TrsmArgs<T>& args, hipStream_t stream);
 template <class T>
 void launch_potrf_diag(T* a, int lda, int jb, T* winv_block, int* info, int info_base, hipStream_t stream,
                        bool factor = true);
+
+// Whole diagonal tile (kb x kb, ld) in one resident cooperative launch of ceil(kb/64) workgroups:
+// lower Cholesky factor in place + the ceil(kb/64) inverted diagonal blocks in winv.  sync: device
+// scratch of at least 2*ceil(kb/64) unsigned (zeroed by the launcher on the stream).
+template <class T>
+void launch_potrf_coop(T* tile, int ld, int kb, T* winv, int* info, int info_base, unsigned* sync,
+                       hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------
 // Layout kernels between the caller's column-major local array (staged on the device) and the

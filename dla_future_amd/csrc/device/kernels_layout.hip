@@ -121,11 +121,13 @@ void launch_copy2d(T* dst, long ldd, const T* src, long lds, int rows, int cols,
 void update_kernels_init();
 void trsm_kernels_init();
 void potrf_kernels_init();
+void potrf_coop_kernels_init();
 
 void device_kernels_init() {
   update_kernels_init();
   trsm_kernels_init();
   potrf_kernels_init();
+  potrf_coop_kernels_init();
 }
 
 #define INST(T)                                                                \

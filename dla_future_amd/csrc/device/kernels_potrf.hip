@@ -8,23 +8,9 @@
 // inv(L), which turns every later triangular solve into MFMA GEMMs.
 // A non-positive (or NaN) pivot stores the LAPACK-style global index into *info (first failure
 // wins) -- the device-side replacement of assert_info's printf+trap.
-#include "device_api.hpp"
+#include "potrf_diag_core.hpp"
 
 namespace dlaf_mi355x {
-
-constexpr int kPD = kDiagBlock;  // 64
-constexpr int kPDLd = kPD + 1;   // LDS leading dimension (bank spread for row access)
-constexpr int kPB = 16;          // inner panel width of the in-LDS factorization
-
-// broadcast of one wave lane's double to the whole wave through two v_readlane_b32 (lane uniform)
-__device__ __forceinline__ double lane_bcast(double v, int lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ float lane_bcast(float v, int lane) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
 
 // Structure (all in LDS, 4 waves):
 //   factor : for each 16-column panel: left-looking update by all threads, then the unblocked
@@ -45,7 +31,6 @@ __global__ __launch_bounds__(kThreads) void potrf_diag_kernel(T* __restrict__ a,
   R* Wim = Wre + kPD * kPDLd;
   __shared__ int fail_col;
   const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
 
   if (*info != 0)
     return;
@@ -72,224 +57,14 @@ __global__ __launch_bounds__(kThreads) void potrf_diag_kernel(T* __restrict__ a,
   }
   __syncthreads();
 
-  // ---- factorization ------------------------------------------------------------------------------
-  for (int p0 = 0; factor && p0 < jb; p0 += kPB) {
-    // (1) left-looking update of panel columns [p0, p0+16) with the finished columns [0, p0)
-    if (p0 > 0) {
-      const int r = lane;             // row
-      const int cq = wave * 4;        // 4 columns per thread
-      if (r >= p0) {
-        R sre[4] = {0, 0, 0, 0}, sim[4] = {0, 0, 0, 0};
-        for (int k = 0; k < p0; ++k) {
-          const R lr_re = Lre[k * kPDLd + r];
-          R lr_im = 0;
-          if constexpr (CX)
-            lr_im = Lim[k * kPDLd + r];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int c = p0 + cq + q;
-            const R lc_re = Lre[k * kPDLd + c];
-            if constexpr (CX) {
-              const R lc_im = Lim[k * kPDLd + c];
-              sre[q] += lr_re * lc_re + lr_im * lc_im;   // l_r * conj(l_c)
-              sim[q] += lr_im * lc_re - lr_re * lc_im;
-            }
-            else {
-              sre[q] += lr_re * lc_re;
-            }
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int c = p0 + cq + q;
-          if (r >= c) {
-            Lre[c * kPDLd + r] -= sre[q];
-            if constexpr (CX)
-              if (r != c)
-                Lim[c * kPDLd + r] -= sim[q];
-          }
-        }
-      }
-      __syncthreads();
-    }
-    // (2) unblocked factorization of the panel by wave 0: lane r holds row r of the panel
-    if (wave == 0) {
-      const int r = lane;
-      R are[kPB], aim[kPB];
-#pragma unroll
-      for (int c = 0; c < kPB; ++c) {
-        are[c] = Lre[(p0 + c) * kPDLd + r];
-        aim[c] = CX ? Lim[(p0 + c) * kPDLd + r] : R(0);
-      }
-      int failed = -1;
-#pragma unroll
-      for (int c = 0; c < kPB; ++c) {
-        const int pr = p0 + c;  // pivot row == pivot column (global in the block)
-        if (pr < jb && failed < 0) {
-          const R d = lane_bcast(are[c], pr);
-          if (!(d > R(0))) {
-            failed = pr;
-          }
-          else {
-            const R sq = sqrt(d);
-            if (r == pr) {
-              are[c] = sq;
-              aim[c] = 0;
-            }
-            else if (r > pr) {
-              are[c] = are[c] / sq;
-              if constexpr (CX)
-                aim[c] = aim[c] / sq;
-            }
-#pragma unroll
-            for (int j = c + 1; j < kPB; ++j) {
-              // l_j = L[p0+j][pr]: held by lane p0+j in are[c]
-              const R lj_re = lane_bcast(are[c], p0 + j);
-              R lj_im = 0;
-              if constexpr (CX)
-                lj_im = lane_bcast(aim[c], p0 + j);
-              if (r >= p0 + j) {
-                if constexpr (CX) {
-                  are[j] -= are[c] * lj_re + aim[c] * lj_im;
-                  aim[j] -= aim[c] * lj_re - are[c] * lj_im;
-                }
-                else {
-                  are[j] -= are[c] * lj_re;
-                }
-              }
-            }
-          }
-        }
-      }
-      if (failed >= 0) {
-        if (lane == 0) {
-          fail_col = failed;
-          atomicCAS(info, 0, info_base + failed + 1);
-        }
-      }
-      else {
-#pragma unroll
-        for (int c = 0; c < kPB; ++c) {
-          if (r >= p0 + c) {
-            Lre[(p0 + c) * kPDLd + r] = are[c];
-            if constexpr (CX)
-              Lim[(p0 + c) * kPDLd + r] = (r == p0 + c) ? R(0) : aim[c];
-          }
-        }
-      }
-    }
-    __syncthreads();
-    if (fail_col >= 0)
-      return;
-  }
-
-  // ---- W = inv(L) -----------------------------------------------------------------------------------
-  // (a) diagonal 16x16 blocks: wave w inverts block w; lane c < 16 owns column c of the block
+  // ---- factor + invert in LDS ------------------------------------------------------------------------
   {
-    const int b0 = wave * kPB;
-    if (lane < kPB && b0 < jb) {
-      const int c = lane;
-      R wre[kPB], wim[kPB];
-#pragma unroll
-      for (int i = 0; i < kPB; ++i) {
-        R sre = (i == c) ? R(1) : R(0), sim = 0;
-#pragma unroll
-        for (int k = 0; k < i; ++k) {
-          // only k >= c contribute (w[k] = 0 above the diagonal)
-          const R l_re = Lre[(b0 + k) * kPDLd + b0 + i];
-          if constexpr (CX) {
-            const R l_im = Lim[(b0 + k) * kPDLd + b0 + i];
-            sre -= l_re * wre[k] - l_im * wim[k];
-            sim -= l_re * wim[k] + l_im * wre[k];
-          }
-          else {
-            sre -= l_re * wre[k];
-          }
-        }
-        const R dd = Lre[(b0 + i) * kPDLd + b0 + i];
-        if constexpr (CX) {
-          const R di = Lim[(b0 + i) * kPDLd + b0 + i];
-          if (di == R(0)) {
-            wre[i] = sre / dd;
-            wim[i] = sim / dd;
-          }
-          else {
-            const R den = dd * dd + di * di;
-            wre[i] = (sre * dd + sim * di) / den;
-            wim[i] = (sim * dd - sre * di) / den;
-          }
-        }
-        else {
-          wre[i] = sre / dd;
-          wim[i] = 0;
-        }
-        if (i < c) {  // strictly upper part of the column is zero
-          wre[i] = 0;
-          wim[i] = 0;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < kPB; ++i) {
-        Wre[(b0 + c) * kPDLd + b0 + i] = wre[i];
-        if constexpr (CX)
-          Wim[(b0 + c) * kPDLd + b0 + i] = wim[i];
-      }
+    const int failed = diag_factor_invert<T>(Lre, Lim, Wre, Wim, jb, factor, &fail_col);
+    if (failed >= 0) {
+      if (t == 0)
+        atomicCAS(info, 0, info_base + failed + 1);
+      return;
     }
-  }
-  __syncthreads();
-  // (b) off-diagonal blocks by block distance d: W(i,j) = -W(i,i) * sum_{k=j}^{i-1} L(i,k) W(k,j), i = j+d.
-  // One thread per element of a 16x16 block; the inner sums go through the T scratch (reusing the
-  // strictly upper part of W's LDS image is avoided: T lives in the im plane of nothing -> use regs + LDS row).
-  R* Tre = Wre + kPD * kPDLd * (CX ? 2 : 1);  // 3 x 16 x 16 scratch (allocated behind W)
-  R* Tim = Tre + 3 * kPB * kPB;
-  const int ti = t % kPB, tj = t / kPB;  // element (ti, tj) of a block
-  for (int d = 1; d < kPD / kPB; ++d) {
-    const int nblk = kPD / kPB - d;
-    for (int j = 0; j < nblk; ++j) {
-      const int i = j + d;
-      const int r0 = i * kPB, c0 = j * kPB;
-      R sre = 0, sim = 0;
-      for (int k = c0; k < r0; ++k) {  // k runs over columns of L(i, j..i-1) = rows of W(j..i-1, j)
-        const R l_re = Lre[k * kPDLd + r0 + ti];
-        const R w_re = Wre[(c0 + tj) * kPDLd + k];
-        if constexpr (CX) {
-          const R l_im = Lim[k * kPDLd + r0 + ti];
-          const R w_im = Wim[(c0 + tj) * kPDLd + k];
-          sre += l_re * w_re - l_im * w_im;
-          sim += l_re * w_im + l_im * w_re;
-        }
-        else {
-          sre += l_re * w_re;
-        }
-      }
-      Tre[j * kPB * kPB + tj * kPB + ti] = sre;
-      if constexpr (CX)
-        Tim[j * kPB * kPB + tj * kPB + ti] = sim;
-    }
-    __syncthreads();
-    for (int j = 0; j < nblk; ++j) {
-      const int i = j + d;
-      const int r0 = i * kPB, c0 = j * kPB;
-      R sre = 0, sim = 0;
-#pragma unroll
-      for (int k = 0; k < kPB; ++k) {
-        const R w_re = Wre[(r0 + k) * kPDLd + r0 + ti];  // W(i,i)[ti][k]
-        const R t_re = Tre[j * kPB * kPB + tj * kPB + k];
-        if constexpr (CX) {
-          const R w_im = Wim[(r0 + k) * kPDLd + r0 + ti];
-          const R t_im = Tim[j * kPB * kPB + tj * kPB + k];
-          sre += w_re * t_re - w_im * t_im;
-          sim += w_re * t_im + w_im * t_re;
-        }
-        else {
-          sre += w_re * t_re;
-        }
-      }
-      Wre[(c0 + tj) * kPDLd + r0 + ti] = -sre;
-      if constexpr (CX)
-        Wim[(c0 + tj) * kPDLd + r0 + ti] = -sim;
-    }
-    __syncthreads();
   }
 
   // ---- write back: lower triangle of L, dense 64x64 W --------------------------------------------
@@ -313,9 +88,7 @@ __global__ __launch_bounds__(kThreads) void potrf_diag_kernel(T* __restrict__ a,
 
 template <class T>
 static constexpr int potrf_lds_bytes() {
-  // L and W images (re[/im] planes) + the 3 x 16 x 16 scratch blocks of the inversion
-  return ((TypeInfo<T>::is_complex ? 4 : 2) * kPD * kPDLd + (TypeInfo<T>::is_complex ? 2 : 1) * 3 * kPB * kPB) *
-         (int) sizeof(real_t<T>);
+  return diag_lds_elems<T>() * (int) sizeof(real_t<T>);
 }
 
 template <class T>

@@ -1,0 +1,301 @@
+// kernels_potrf_coop.hip -- Cholesky of one diagonal tile (kb x kb, kb <= nb) as ONE resident,
+// cooperative launch: ceil(kb/64) workgroups, workgroup s owns the 64-row strip s of the tile.
+//
+// Reference: tile::potrf (lapack/tile.h:577-606, one rocsolver_*potrf call).  The first version of
+// this build issued ~3 dependent launches per 64 columns (diagonal block, sub-panel TRSM, in-tile
+// update); measured on MI355X those ~48 launches either leave the GPU idle (serial order) or starve
+// behind the queued workgroups of the bulk trailing update (stream priorities do not pre-empt them).
+// One launch whose few workgroups stay resident has neither problem: it runs beside the bulk update.
+//
+// Right-looking over 64-column steps j; strip s takes part in steps j <= s:
+//   j == s : block (s,s) is final -> factor + invert in LDS (potrf_diag_core.hpp), write L_jj and
+//            inv(L_jj), publish flag[j], done;
+//   j <  s : wait flag[j]; X_s = A(s,j) * inv(L_jj)^H (MFMA); store X_s; arrive on cnt[j]; wait until
+//            all strips below j arrived; A(s,c) -= X_s * X_c^H for c = j+1..s (MFMA, X_s kept in LDS).
+// Inter-workgroup hand-offs follow the placement-independent protocol of the CDNA4 guide
+// (cdna_hip_programming.md, Guideline 16): every storing wave drains vmcnt, workgroup barrier, one lane
+// agent-scope release fence + drained wait + relaxed agent atomic; the consumer polls relaxed, then one
+// agent-scope acquire fence, drained wait, workgroup barrier, plain loads.  Every spin is bounded.
+#include "potrf_diag_core.hpp"
+
+namespace dlaf_mi355x {
+
+constexpr int kCB = kDiagBlock;  // 64
+
+template <class T>
+struct CoopCfg {
+  using R = real_t<T>;
+  static constexpr bool CX = TypeInfo<T>::is_complex;
+  static constexpr int NPL = CX ? 2 : 1;
+  // operand images [k][64 + pad]; complex<double> has no room for the pad in 160 KiB of LDS
+  static constexpr int PAD = (CX && sizeof(R) == 8) ? 0 : 16;
+  static constexpr int LD = kCB + PAD;
+  static constexpr int IMG = kCB * LD;              // one plane of one operand
+  static constexpr int OPERANDS = 2 * NPL * IMG;    // A and B images
+  static constexpr int ELEMS = OPERANDS > diag_lds_elems<T>() ? OPERANDS : diag_lds_elems<T>();
+  static constexpr int LDS_BYTES = ELEMS * (int) sizeof(R);
+};
+
+constexpr unsigned kCoopFailed = 0x40000000u;
+constexpr long kCoopSpinLimit = 40000000;  // x (s_sleep + L2 round trip) >> any legitimate wait
+
+// all threads call; publishes AFTER every global store of the workgroup is visible agent-wide
+__device__ __forceinline__ void coop_publish(unsigned* word, unsigned value, bool add) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (add)
+      __hip_atomic_fetch_add(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+      __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// all threads call; returns the observed value (>= target), or 0xFFFFFFFF after the spin bound
+__device__ __forceinline__ unsigned coop_wait(unsigned* word, unsigned target, unsigned* shared_slot) {
+  if (threadIdx.x == 0) {
+    unsigned v;
+    long spins = 0;
+    while ((v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
+      __builtin_amdgcn_s_sleep(16);
+      if (++spins > kCoopSpinLimit) {
+        v = 0xFFFFFFFFu;
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    *shared_slot = v;
+  }
+  __syncthreads();
+  const unsigned r = *shared_slot;
+  __syncthreads();
+  return r;
+}
+
+// global (rows x cols, ld) block -> LDS operand image [k = col][m = row], zero-filled to 64 x 64
+template <class T>
+__device__ __forceinline__ void coop_load_image(real_t<T>* img, const T* g, long ld, int rows, int cols) {
+  using C = CoopCfg<T>;
+  for (int idx = threadIdx.x; idx < kCB * kCB; idx += kThreads) {
+    const int m = idx % kCB, k = idx / kCB;
+    T v = zero_el<T>();
+    if (m < rows && k < cols)
+      v = g[m + (long) k * ld];
+    img[k * C::LD + m] = re_of(v);
+    if constexpr (C::CX)
+      img[C::IMG + k * C::LD + m] = im_of(v);
+  }
+}
+
+// acc(m = wave*16 + c, n = j*16 + irow(g, v)) = sum_k A[m][k] * conj(B[n][k]) over the 64 x 64 images
+template <class T>
+__device__ __forceinline__ void coop_mma64(const real_t<T>* A, const real_t<T>* B,
+                                           typename Mma<real_t<T>>::acc_t (&re)[4],
+                                           typename Mma<real_t<T>>::acc_t (&im)[4]) {
+  using C = CoopCfg<T>;
+  using R = real_t<T>;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    re[j] = typename Mma<R>::acc_t{0, 0, 0, 0};
+    im[j] = typename Mma<R>::acc_t{0, 0, 0, 0};
+  }
+#pragma unroll 4
+  for (int k4 = 0; k4 < kCB / 4; ++k4) {
+    const int kk = 4 * k4 + g;
+    const R a_re = A[kk * C::LD + wave * 16 + c];
+    R a_im = 0;
+    if constexpr (C::CX)
+      a_im = A[C::IMG + kk * C::LD + wave * 16 + c];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const R b_re = B[kk * C::LD + j * 16 + c];
+      re[j] = Mma<R>::mma(b_re, a_re, re[j]);
+      if constexpr (C::CX) {
+        const R b_im = B[C::IMG + kk * C::LD + j * 16 + c];
+        re[j] = Mma<R>::mma(b_im, a_im, re[j]);
+        im[j] = Mma<R>::mma(b_re, a_im, im[j]);
+        im[j] = Mma<R>::mma(b_im, -a_re, im[j]);
+      }
+    }
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(kThreads, 1) void potrf_coop_kernel(T* __restrict__ tile, int ld, int kb,
+                                                                  T* __restrict__ winv, int* info, int info_base,
+                                                                  unsigned* sync) {
+  using C = CoopCfg<T>;
+  using R = real_t<T>;
+  using acc_t = typename Mma<R>::acc_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  R* lds = reinterpret_cast<R*>(lds_raw);
+  __shared__ int fail_col;
+  __shared__ unsigned wait_slot;
+  const int G = gridDim.x, s = blockIdx.x;
+  unsigned* flag = sync;     // flag[j] = 1: L_jj and inv(L_jj) are in memory;  kCoopFailed: not SPD
+  unsigned* cnt = sync + G;  // cnt[j]: strips whose X(.,j) is in memory
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int rows_s = min(kCB, kb - kCB * s);
+
+  if (*info != 0)
+    return;
+
+  R* Aimg = lds;
+  R* Bimg = lds + C::NPL * C::IMG;
+
+  for (int j = 0; j < s; ++j) {
+    const int jb = kCB;  // every block column left of my diagonal block is full
+    const unsigned f = coop_wait(&flag[j], 1u, &wait_slot);
+    if (f != 1u)
+      return;  // not positive definite (info already set by the owner) or spin bound hit
+    // ---- X_s = A(s,j) * inv(L_jj)^H ----------------------------------------------------------------
+    T* Asj = tile + (long) kCB * s + (long) kCB * j * ld;
+    coop_load_image<T>(Aimg, Asj, ld, rows_s, jb);
+    coop_load_image<T>(Bimg, winv + (long) j * kCB * kCB, kCB, kCB, kCB);
+    __syncthreads();
+    acc_t xre[4], xim[4];
+    coop_mma64<T>(Aimg, Bimg, xre, xim);
+    __syncthreads();  // every wave is done reading the A image before it is overwritten with X_s
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int m = wave * 16 + c, n = jt * 16 + Mma<R>::irow(g, v);
+        // X_s stays in LDS as the row operand of this step's updates: image [k = n][m]
+        Aimg[n * C::LD + m] = xre[jt][v];
+        if constexpr (C::CX)
+          Aimg[C::IMG + n * C::LD + m] = xim[jt][v];
+        if (m < rows_s)
+          Asj[m + (long) n * ld] = make_el<T>(xre[jt][v], C::CX ? xim[jt][v] : R(0));
+      }
+    coop_publish(&cnt[j], 1u, true);
+    const unsigned arrived = coop_wait(&cnt[j], (unsigned) (G - 1 - j), &wait_slot);
+    if (arrived == 0xFFFFFFFFu)
+      return;
+    // ---- A(s,c) -= X_s * X_c^H for c = j+1 .. s ----------------------------------------------------
+    for (int cc = j + 1; cc <= s; ++cc) {
+      const int rows_c = min(kCB, kb - kCB * cc);
+      coop_load_image<T>(Bimg, tile + (long) kCB * cc + (long) kCB * j * ld, ld, rows_c, jb);
+      __syncthreads();
+      acc_t ure[4], uim[4];
+      coop_mma64<T>(Aimg, Bimg, ure, uim);
+      T* Csc = tile + (long) kCB * s + (long) kCB * cc * ld;
+      const bool diag = (cc == s);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int m = wave * 16 + c, n = jt * 16 + Mma<R>::irow(g, v);
+          if (m < rows_s && n < rows_c && (!diag || m >= n)) {
+            T cv = Csc[m + (long) n * ld];
+            if constexpr (C::CX) {
+              cv = T{cv.re - ure[jt][v], (diag && m == n) ? R(0) : cv.im - uim[jt][v]};
+            }
+            else {
+              cv = cv - ure[jt][v];
+            }
+            Csc[m + (long) n * ld] = cv;
+          }
+        }
+      __syncthreads();  // B image is reloaded by the next iteration
+    }
+    // my own stores to block (s, .) must be visible to my own later loads: same CU, ordered by the
+    // barrier above; the next step's first action is a wait on flag[j+1] anyway
+  }
+
+  // ---- j == s: my diagonal block is final ---------------------------------------------------------
+  {
+    R* Lre = lds;
+    R* Lim = Lre + kPD * kPDLd;
+    R* Wre = Lre + C::NPL * kPD * kPDLd;
+    R* Wim = Wre + kPD * kPDLd;
+    T* Ass = tile + (long) kCB * s + (long) kCB * s * ld;
+    const int jb = rows_s;
+    if (t == 0)
+      fail_col = -1;
+    // make sure my own updates of block (s,s) (plain stores of this workgroup) are complete
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int idx = t; idx < kPD * kPD; idx += kThreads) {
+      const int r = idx % kPD, cl = idx / kPD;
+      R re = 0, imv = 0;
+      if (r < jb && cl < jb && r >= cl) {
+        const T v = Ass[r + (long) cl * ld];
+        re = re_of(v);
+        imv = im_of(v);
+      }
+      if (r == cl && r >= jb)
+        re = 1;
+      Lre[cl * kPDLd + r] = re;
+      if constexpr (C::CX)
+        Lim[cl * kPDLd + r] = (r == cl) ? R(0) : imv;
+      Wre[cl * kPDLd + r] = 0;
+      if constexpr (C::CX)
+        Wim[cl * kPDLd + r] = 0;
+    }
+    __syncthreads();
+    const int failed = diag_factor_invert<T>(Lre, Lim, Wre, Wim, jb, 1, &fail_col);
+    if (failed >= 0) {
+      if (t == 0)
+        atomicCAS(info, 0, info_base + kCB * s + failed + 1);
+      coop_publish(&flag[s], kCoopFailed, false);
+      return;
+    }
+    T* Ws = winv + (long) s * kCB * kCB;
+    for (int idx = t; idx < kPD * kPD; idx += kThreads) {
+      const int rr = idx % kPD, cl = idx / kPD;
+      if (rr < jb && cl < jb && rr >= cl) {
+        R imv = 0;
+        if constexpr (C::CX)
+          imv = Lim[cl * kPDLd + rr];
+        Ass[rr + (long) cl * ld] = make_el<T>(Lre[cl * kPDLd + rr], imv);
+      }
+      R wre = 0, wim = 0;
+      if (rr < jb && cl < jb) {
+        wre = Wre[cl * kPDLd + rr];
+        if constexpr (C::CX)
+          wim = Wim[cl * kPDLd + rr];
+      }
+      Ws[rr + (long) cl * kPD] = make_el<T>(wre, wim);
+    }
+    coop_publish(&flag[s], 1u, false);
+  }
+}
+
+template <class T>
+void launch_potrf_coop(T* tile, int ld, int kb, T* winv, int* info, int info_base, unsigned* sync,
+                       hipStream_t stream) {
+  if (kb <= 0)
+    return;
+  const int G = (kb + kCB - 1) / kCB;
+  (void) hipMemsetAsync(sync, 0, sizeof(unsigned) * 2 * (size_t) G, stream);
+  hipLaunchKernelGGL((potrf_coop_kernel<T>), dim3((unsigned) G), dim3(kThreads), CoopCfg<T>::LDS_BYTES, stream, tile, ld,
+                     kb, winv, info, info_base, sync);
+}
+
+template <class T>
+static void coop_init_one() {
+  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_coop_kernel<T>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, CoopCfg<T>::LDS_BYTES);
+}
+
+void potrf_coop_kernels_init() {
+  coop_init_one<float>();
+  coop_init_one<double>();
+  coop_init_one<cfloat>();
+  coop_init_one<cdouble>();
+}
+
+template void launch_potrf_coop<float>(float*, int, int, float*, int*, int, unsigned*, hipStream_t);
+template void launch_potrf_coop<double>(double*, int, int, double*, int*, int, unsigned*, hipStream_t);
+template void launch_potrf_coop<cfloat>(cfloat*, int, int, cfloat*, int*, int, unsigned*, hipStream_t);
+template void launch_potrf_coop<cdouble>(cdouble*, int, int, cdouble*, int*, int, unsigned*, hipStream_t);
+
+}  // namespace dlaf_mi355x

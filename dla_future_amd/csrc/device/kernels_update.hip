@@ -49,23 +49,19 @@ struct UpdateMap {
   int xcd;       // remap blockIdx so each XCD works on consecutive patches
   int RB, CB;    // block rows / cols of the domain
   int bpt_m, bpt_n;
+  long total;    // work items (blocks of the patch enumeration)
+  int persist;   // != 0: the grid is smaller than `total`; workgroups pull work items from `counters`
+  unsigned* counters;  // persist: 8 (per workgroup-id-mod-8, i.e. per XCD) or 1 dequeue heads, zeroed per launch
 };
 
-// ROLE only names the instantiation (0 trailing bulk, 1 lookahead column, 2 in-tile POTRF update) so
-// that rocprof statistics and the library's own HIP-event timing refer to the same set of launches
-template <class T, bool VEC, int ROLE>
-__global__ __launch_bounds__(kThreads, UpdateCfg<T>::min_waves) void update_kernel(UpdateArgs<T> p, UpdateMap mp) {
+// One work item = one BM x BN block of one tile.  Returns early for blocks outside the domain.
+template <class T, bool VEC>
+__device__ __forceinline__ void update_block(const UpdateArgs<T>& p, const UpdateMap& mp, long w,
+                                             real_t<T>* __restrict__ lds) {
   using Cfg = typename UpdateCfg<T>::type;
   using R = real_t<T>;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  R* lds = reinterpret_cast<R*>(lds_raw);
 
-  if (*p.info != 0)
-    return;
-
-  // ---- which block am I ------------------------------------------------------------------
-  const unsigned b = blockIdx.x;
-  const long w = mp.xcd ? (long) (b & 7u) * (gridDim.x >> 3) + (b >> 3) : (long) b;
+  // ---- which block is work item w ----------------------------------------------------------
   const int ps = mp.ps;
   const long patch = w >> (2 * ps);
   const int q = (int) (w & ((1 << (2 * ps)) - 1));
@@ -203,13 +199,50 @@ __global__ __launch_bounds__(kThreads, UpdateCfg<T>::min_waves) void update_kern
   }
 }
 
+// ROLE only names the instantiation (0 trailing bulk, 1 lookahead column, 2 in-tile POTRF update) so
+// that rocprof statistics and the library's own HIP-event timing refer to the same set of launches.
+// Work item v -> block w: the 8 XCDs (workgroup id mod 8 under round-robin dispatch) get contiguous runs
+// of 8x8-block patches.  Persistent form: gridDim.x workgroups stride over the work items, which (a)
+// leaves the compute units the launcher did not ask for free for the resident POTRF / RCCL kernels
+// that must run beside the bulk update and (b) keeps each XCD on neighbouring patches.
+template <class T, bool VEC, int ROLE>
+__global__ __launch_bounds__(kThreads, UpdateCfg<T>::min_waves) void update_kernel(UpdateArgs<T> p, UpdateMap mp) {
+  using R = real_t<T>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  R* lds = reinterpret_cast<R*>(lds_raw);
+  if (*p.info != 0)
+    return;
+  if (!mp.persist) {
+    const long v = blockIdx.x;
+    const long w = mp.xcd ? (v & 7) * (mp.total >> 3) + (v >> 3) : v;
+    update_block<T, VEC>(p, mp, w, lds);
+    return;
+  }
+  // persistent: workgroups with the same id mod 8 (same XCD under round-robin dispatch) drain the
+  // same contiguous range of work items in order through one dequeue head per range
+  __shared__ unsigned next_item;
+  const int nq = mp.xcd ? 8 : 1;
+  const long per_q = mp.total / nq;
+  const int q = mp.xcd ? (int) (blockIdx.x & 7) : 0;
+  for (;;) {
+    if (threadIdx.x == 0)
+      next_item = atomicAdd(&mp.counters[q], 1u);
+    __syncthreads();
+    const long i = next_item;
+    __syncthreads();
+    if (i >= per_q)
+      break;
+    update_block<T, VEC>(p, mp, (long) q * per_q + i, lds);
+  }
+}
+
 template <class T>
 static bool aligned16(const void* ptr, long stride_elems) {
   return (reinterpret_cast<uintptr_t>(ptr) % 16 == 0) && ((stride_elems * (long) sizeof(T)) % 16 == 0);
 }
 
 template <class T>
-void launch_update(const UpdateArgs<T>& a, hipStream_t stream, int role) {
+void launch_update(const UpdateArgs<T>& a, hipStream_t stream, int role, long max_blocks, unsigned* counters) {
   using Cfg = typename UpdateCfg<T>::type;
   if (a.il1 <= a.il0 || a.jl1 <= a.jl0 || a.K <= 0 || a.nb <= 0)
     return;
@@ -224,8 +257,19 @@ void launch_update(const UpdateArgs<T>& a, hipStream_t stream, int role) {
   mp.PR = (mp.RB + psz - 1) / psz;
   const int PC = (mp.CB + psz - 1) / psz;
   const long npatch = mp.tri ? (long) mp.PR * (mp.PR + 1) / 2 : (long) mp.PR * PC;
-  const long grid = npatch << (2 * mp.ps);
+  mp.total = npatch << (2 * mp.ps);
   mp.xcd = (mp.ps > 0) ? 1 : 0;
+  long grid = mp.total;
+  mp.persist = 0;
+  mp.counters = nullptr;
+  if (max_blocks > 0 && counters != nullptr && mp.total > max_blocks) {
+    grid = mp.xcd ? (max_blocks / 8) * 8 : max_blocks;  // equal number of workgroups per XCD range
+    if (grid < 8)
+      grid = 8;
+    mp.persist = 1;
+    mp.counters = counters;
+    (void) hipMemsetAsync(counters, 0, 8 * sizeof(unsigned), stream);
+  }
   const bool vec = aligned16<T>(a.a, a.lda) && aligned16<T>(a.a, a.a_ts) && aligned16<T>(a.b, a.ldb) &&
                    aligned16<T>(a.b, a.b_ts);
   auto go = [&](auto vtag, auto rtag) {
@@ -244,6 +288,17 @@ void launch_update(const UpdateArgs<T>& a, hipStream_t stream, int role) {
     by_role(std::true_type{});
   else
     by_role(std::false_type{});
+}
+
+// resident workgroups per compute unit of the bulk instantiation (for sizing persistent grids)
+template <class T>
+int update_blocks_per_cu() {
+  using Cfg = typename UpdateCfg<T>::type;
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&update_kernel<T, true, 0>), kThreads,
+                                                   Cfg::LDS_BYTES) != hipSuccess || n < 1)
+    n = 1;
+  return n;
 }
 
 template <class T>
@@ -268,9 +323,13 @@ void update_kernels_init() {
   update_init_one<cdouble>();
 }
 
-template void launch_update<float>(const UpdateArgs<float>&, hipStream_t, int);
-template void launch_update<double>(const UpdateArgs<double>&, hipStream_t, int);
-template void launch_update<cfloat>(const UpdateArgs<cfloat>&, hipStream_t, int);
-template void launch_update<cdouble>(const UpdateArgs<cdouble>&, hipStream_t, int);
+template void launch_update<float>(const UpdateArgs<float>&, hipStream_t, int, long, unsigned*);
+template int update_blocks_per_cu<float>();
+template void launch_update<double>(const UpdateArgs<double>&, hipStream_t, int, long, unsigned*);
+template int update_blocks_per_cu<double>();
+template void launch_update<cfloat>(const UpdateArgs<cfloat>&, hipStream_t, int, long, unsigned*);
+template int update_blocks_per_cu<cfloat>();
+template void launch_update<cdouble>(const UpdateArgs<cdouble>&, hipStream_t, int, long, unsigned*);
+template int update_blocks_per_cu<cdouble>();
 
 }  // namespace dlaf_mi355x

@@ -147,8 +147,16 @@ void DeviceMatrix<T>::create(Grid* g, char uplo_, long n_, int nb_, int isrc, in
       panelT[b] = dev_alloc<T>((size_t) ltc * tile_elems);
     }
   }
+  {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    DLAF_HIP_CHECK(hipGetDevice(&dev));
+    DLAF_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    bulk_slots = (long) prop.multiProcessorCount * update_blocks_per_cu<T>();
+  }
   DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&info), sizeof(int)));
   DLAF_HIP_CHECK(hipMemset(info, 0, sizeof(int)));
+  DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&coop_sync), sizeof(unsigned) * (2 * (size_t) (nb / kDiagBlock + 2) + 8)));
   DLAF_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&info_host), sizeof(int), hipHostMallocDefault));
   *info_host = 0;
 
@@ -225,6 +233,7 @@ void DeviceMatrix<T>::destroy() {
   if (staging)
     (void) hipFree(staging);
   (void) hipFree(info);
+  (void) hipFree(coop_sync);
   (void) hipHostFree(info_host);
   tiles = nullptr;
 }
@@ -336,9 +345,23 @@ void DeviceMatrix<T>::prof_end(int kind, hipStream_t s, double flops, double byt
 // sub-panel solve (TRSM kernel, one column block), in-tile trailing update (update kernel).
 // winv receives the ceil(kb/64) inverted diagonal blocks.  Replaces rocsolver potrf
 // (lapack/tile.h:577-606).
+static bool potrf_use_chain() {
+  static const bool chain = [] {
+    const char* e = std::getenv("DLAF_MI355X_POTRF");
+    return e && std::strcmp(e, "chain") == 0;
+  }();
+  return chain;
+}
+
 template <class T>
-static void potrf_tile(T* t, int ld, int kb, T* winv, int* info, int info_base, hipStream_t s) {
+static void potrf_tile(T* t, int ld, int kb, T* winv, int* info, int info_base, unsigned* sync, hipStream_t s) {
   constexpr int JB = kDiagBlock;
+  if (!potrf_use_chain()) {
+    // one resident cooperative launch (kernels_potrf_coop.hip); DLAF_MI355X_POTRF=chain selects the
+    // multi-launch form below (diagonal block kernel + TRSM kernel + update kernel per 64 columns)
+    launch_potrf_coop(t, ld, kb, winv, info, info_base, sync, s);
+    return;
+  }
   for (int j0 = 0; j0 < kb; j0 += JB) {
     const int jb = std::min(JB, kb - j0);
     T* djj = t + j0 + (size_t) j0 * ld;
@@ -460,7 +483,8 @@ void DeviceMatrix<T>::factorize_async() {
     bool valid = false;
   };
 
-  auto update = [&](const Step& st, long j0, long j1, hipStream_t s, int role) {
+  // reserve: workgroup slots the launch must leave free (resident POTRF / RCCL kernels run beside it)
+  auto update = [&](const Step& st, long j0, long j1, hipStream_t s, int role, long reserve) {
     if (!st.valid || j0 >= j1)
       return;
     // rows that can hold tiles on/below the diagonal of column block j0
@@ -494,7 +518,8 @@ void DeviceMatrix<T>::factorize_async() {
     double fl, by;
     update_work(il0, j0, j1, st.kb, fl, by);
     prof_begin(role, s);
-    launch_update(ua, s, role);
+    launch_update(ua, s, role, reserve > 0 ? std::max<long>(8, bulk_slots - reserve) : 0,
+                  coop_sync + 2 * (nb / kDiagBlock + 2));
     prof_end(role, s, fl, by);
   };
 
@@ -504,6 +529,19 @@ void DeviceMatrix<T>::factorize_async() {
     if (const char* e = std::getenv("DLAF_MI355X_LOOKAHEAD_FLOPS"))
       return std::atof(e);
     return 90e-6 * ((double) nb / kDiagBlock) * 55e12;
+  }();
+
+  // Workgroup slots kept free by the bulk launches: rest_A runs beside the cooperative POTRF of the
+  // next diagonal tile (one workgroup per 64 rows), rest_B beside the RCCL broadcasts of the step.
+  const long potrf_slots = [&]() -> long {
+    if (const char* e = std::getenv("DLAF_MI355X_POTRF_SLOTS"))
+      return std::atol(e);
+    return potrf_use_chain() ? 0 : 2 * ((nb + kDiagBlock - 1) / kDiagBlock);
+  }();
+  const long comm_slots = [&]() -> long {
+    if (const char* e = std::getenv("DLAF_MI355X_COMM_SLOTS"))
+      return std::atol(e);
+    return (dist && tr->device_side()) ? 32 : 0;
   }();
 
   Step prev;  // step k-1, whose rest_B is still to be issued
@@ -524,15 +562,15 @@ void DeviceMatrix<T>::factorize_async() {
       T* tkk = tile(rows.local_of(k), klc);
       const double cxf = TypeInfo<T>::is_complex ? 4.0 : 1.0;
       prof_begin(3, s_panel);
-      potrf_tile(tkk, nb, kb, winv, info, (int) (k * nb), s_panel);
+      potrf_tile(tkk, nb, kb, winv, info, (int) (k * nb), coop_sync, s_panel);
       prof_end(3, s_panel, cxf * (double) kb * kb * kb / 3.0, (double) kb * kb * sizeof(T));
       Lkk = tkk;
       Wkk = winv;
     }
     if (k == nt - 1) {
       // nothing trails the last diagonal tile; flush what is left of step k-1
-      update(prev, prev.rest0, prev.split, s_main, 0);
-      update(prev, prev.split, ltc, s_main, 0);
+      update(prev, prev.rest0, prev.split, s_main, 0, potrf_slots);
+      update(prev, prev.split, ltc, s_main, 0, comm_slots);
       prev.valid = false;
       DLAF_HIP_CHECK(hipEventRecord(ev_diag[k], s_panel));
       DLAF_HIP_CHECK(hipStreamWaitEvent(s_main, ev_diag[k], 0));
@@ -557,7 +595,7 @@ void DeviceMatrix<T>::factorize_async() {
     }
 
     // ---- s_main: first slice of the previous step's bulk update runs beside the POTRF chain -----------
-    update(prev, prev.rest0, prev.split, s_main, 0);
+    update(prev, prev.rest0, prev.split, s_main, 0, potrf_slots);
 
     // ---- s_main: panel TRSM ------------------------------------------------------------------------------
     DLAF_HIP_CHECK(hipStreamWaitEvent(s_main, ev_diag[k], 0));
@@ -632,14 +670,14 @@ void DeviceMatrix<T>::factorize_async() {
       DLAF_HIP_CHECK(hipEventRecord(ev_bcast[k], s_comm));
 
     // ---- s_main: rest of step k-1 (the broadcasts of step k fly underneath) ---------------------------
-    update(prev, prev.split, ltc, s_main, 0);
+    update(prev, prev.split, ltc, s_main, 0, comm_slots);
     if (dist)
       DLAF_HIP_CHECK(hipStreamWaitEvent(s_main, ev_bcast[k], 0));
 
     // ---- s_main: lookahead column of step k, then split the rest ------------------------------------
     cur.rest0 = jl_n;
     if (cols.mine(k + 1) && jl_n < ltc) {
-      update(cur, jl_n, jl_n + 1, s_main, 1);
+      update(cur, jl_n, jl_n + 1, s_main, 1, 0);
       cur.rest0 = jl_n + 1;
     }
     DLAF_HIP_CHECK(hipEventRecord(ev_high[k], s_main));
@@ -715,12 +753,13 @@ int tile_potrf(char uplo, int n, T* a, int lda) {
   hipStream_t s = nullptr;
   DevBuf<T> da((size_t) n * n), tmp((size_t) n * n), w((size_t) ((n + kDiagBlock - 1) / kDiagBlock) * kDiagBlock * kDiagBlock);
   DevBuf<int> info(1);
+  DevBuf<unsigned> sync((size_t) 2 * (n / kDiagBlock + 2));
   DLAF_HIP_CHECK(hipMemsetAsync(info.p, 0, sizeof(int), s));
   // tmp keeps the caller's image (host orientation); da the device orientation
   DLAF_HIP_CHECK(hipMemcpy2DAsync(tmp.p, (size_t) n * sizeof(T), a, (size_t) lda * sizeof(T), (size_t) n * sizeof(T),
                                   (size_t) n, hipMemcpyHostToDevice, s));
   launch_copy2d(da.p, (long) n, tmp.p, (long) n, n, n, tr ? 1 : 0, 0, s);
-  potrf_tile(da.p, n, n, w.p, info.p, 0, s);
+  potrf_tile(da.p, n, n, w.p, info.p, 0, sync.p, s);
   launch_copy2d(tmp.p, (long) n, da.p, (long) n, n, n, tr ? 1 : 0, tr ? 2 : 1, s);
   DLAF_HIP_CHECK(hipMemcpy2DAsync(a, (size_t) lda * sizeof(T), tmp.p, (size_t) n * sizeof(T), (size_t) n * sizeof(T),
                                   (size_t) n, hipMemcpyDeviceToHost, s));

@@ -95,6 +95,7 @@ struct DeviceMatrix : MatrixBase {
   T* panelT[2] = {nullptr, nullptr};  // ltc tiles each (transposed panel)
   T* staging = nullptr;     // column-major staging for upload/download
   size_t staging_elems = 0;
+  unsigned* coop_sync = nullptr;  // flags / counters of the cooperative tile POTRF
   int* info = nullptr;      // device flag
   int* info_host = nullptr; // pinned
 
@@ -111,6 +112,7 @@ struct DeviceMatrix : MatrixBase {
     long launches = 0;
   };
   ProfSlot prof[4];
+  long bulk_slots = 0;  // resident workgroups of the bulk update kernel on this GPU (CUs x blocks per CU)
   bool profiling = true;
   void prof_begin(int kind, hipStream_t s);
   void prof_end(int kind, hipStream_t s, double flops, double bytes);

@@ -15,6 +15,7 @@ int main(int argc, char** argv) {
   const int nt = argc > 1 ? atoi(argv[1]) : 24;
   const int nb = argc > 2 ? atoi(argv[2]) : 1024;
   const int reps = argc > 3 ? atoi(argv[3]) : 3;
+  const long max_blocks = argc > 4 ? atol(argv[4]) : 0;  // > 0: persistent grid of that many workgroups
   update_kernels_init();
   const size_t te = (size_t) nb * nb;
   double* tiles;
@@ -52,16 +53,18 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   (void) hipEventCreate(&e0);
   (void) hipEventCreate(&e1);
-  launch_update(ua, nullptr, 0);
+  unsigned* ctr;
+  (void) hipMalloc(&ctr, 8 * sizeof(unsigned));
+  launch_update(ua, nullptr, 0, max_blocks, ctr);
   (void) hipDeviceSynchronize();
   for (int r = 0; r < reps; ++r) {
     (void) hipEventRecord(e0);
-    launch_update(ua, nullptr, 0);
+    launch_update(ua, nullptr, 0, max_blocks, ctr);
     (void) hipEventRecord(e1);
     (void) hipDeviceSynchronize();
     float ms;
     (void) hipEventElapsedTime(&ms, e0, e1);
-    printf("nt=%d nb=%d: %.3f ms  %.2f TFlop/s\n", nt, nb, ms, flops / ms / 1e9);
+    printf("nt=%d nb=%d max_blocks=%ld: %.3f ms  %.2f TFlop/s\n", nt, nb, max_blocks, ms, flops / ms / 1e9);
   }
   return 0;
 }
