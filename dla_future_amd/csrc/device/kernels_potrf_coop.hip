@@ -13,9 +13,10 @@
 //   j <  s : wait flag[j]; X_s = A(s,j) * inv(L_jj)^H (MFMA); store X_s; arrive on cnt[j]; wait until
 //            all strips below j arrived; A(s,c) -= X_s * X_c^H for c = j+1..s (MFMA, X_s kept in LDS).
 // Inter-workgroup hand-offs follow the placement-independent protocol of the CDNA4 guide
-// (cdna_hip_programming.md, Guideline 16): every storing wave drains vmcnt, workgroup barrier, one lane
-// agent-scope release fence + drained wait + relaxed agent atomic; the consumer polls relaxed, then one
-// agent-scope acquire fence, drained wait, workgroup barrier, plain loads.  Every spin is bounded.
+// (cdna_hip_programming.md, Guideline 16 / split-K recipe): handed-off bytes are write-through (sc1)
+// stores, every storing wave drains vmcnt, workgroup barrier, one relaxed agent atomic; the consumer
+// polls relaxed, then one agent-scope acquire fence, drained wait, workgroup barrier, plain loads.
+// Every spin is bounded.
 #include "potrf_diag_core.hpp"
 
 namespace dlaf_mi355x {
@@ -39,13 +40,39 @@ struct CoopCfg {
 constexpr unsigned kCoopFailed = 0x40000000u;
 constexpr long kCoopSpinLimit = 40000000;  // x (s_sleep + L2 round trip) >> any legitimate wait
 
-// all threads call; publishes AFTER every global store of the workgroup is visible agent-wide
+// Write-through (sc1) store of one element: the bytes another workgroup will read are stored this way,
+// so publishing needs NO agent-scope release fence.  That fence (buffer_wbl2) writes back every dirty
+// line of the XCD's L2 -- beside the bulk trailing update, which keeps megabytes of C tiles dirty, it
+// made each hand-off cost tens of microseconds (POTRF(1024): 1.5 ms alone, 5-7 ms beside the update).
+template <class T>
+__device__ __forceinline__ void store_wt(T* p, const T& v) {
+  if constexpr (sizeof(T) == 4) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  }
+  else if constexpr (sizeof(T) == 8) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  else {
+    struct Two {
+      unsigned long long a, b;
+    };
+    const Two t = __builtin_bit_cast(Two, v);
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+    __hip_atomic_store(q, t.a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, t.b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// all threads call.  Hand-off form "write-through stores + drained flag" (cdna_hip_programming.md,
+// split-K recipe / Guideline 16 R1): every byte a consumer reads was stored with store_wt; every wave
+// drains its stores, the workgroup barrier orders all of them before the one relaxed agent atomic.
+// The consumer polls, then takes ONE agent-scope acquire (L1 invalidate) before plain loads.
 __device__ __forceinline__ void coop_publish(unsigned* word, unsigned value, bool add) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (add)
       __hip_atomic_fetch_add(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else
@@ -75,19 +102,39 @@ __device__ __forceinline__ unsigned coop_wait(unsigned* word, unsigned target, u
   return r;
 }
 
-// global (rows x cols, ld) block -> LDS operand image [k = col][m = row], zero-filled to 64 x 64
+// global (rows x cols, ld) block -> LDS operand image [k = col][m = row], zero-filled to 64 x 64.
+// Two halves so that a caller can keep the 16 loads of a block in flight behind other work: the
+// kernel is latency-bound and, beside the bulk update, a global round trip costs several microseconds.
+constexpr int kCoopPerThread = kCB * kCB / kThreads;  // 16
+
+template <class T>
+__device__ __forceinline__ void coop_fetch(T (&regs)[kCoopPerThread], const T* g, long ld, int rows, int cols) {
+#pragma unroll
+  for (int q = 0; q < kCoopPerThread; ++q) {
+    const int idx = threadIdx.x + q * kThreads;
+    const int m = idx % kCB, k = idx / kCB;
+    regs[q] = (m < rows && k < cols) ? g[m + (long) k * ld] : zero_el<T>();
+  }
+}
+
+template <class T>
+__device__ __forceinline__ void coop_commit(real_t<T>* img, const T (&regs)[kCoopPerThread]) {
+  using C = CoopCfg<T>;
+#pragma unroll
+  for (int q = 0; q < kCoopPerThread; ++q) {
+    const int idx = threadIdx.x + q * kThreads;
+    const int m = idx % kCB, k = idx / kCB;
+    img[k * C::LD + m] = re_of(regs[q]);
+    if constexpr (C::CX)
+      img[C::IMG + k * C::LD + m] = im_of(regs[q]);
+  }
+}
+
 template <class T>
 __device__ __forceinline__ void coop_load_image(real_t<T>* img, const T* g, long ld, int rows, int cols) {
-  using C = CoopCfg<T>;
-  for (int idx = threadIdx.x; idx < kCB * kCB; idx += kThreads) {
-    const int m = idx % kCB, k = idx / kCB;
-    T v = zero_el<T>();
-    if (m < rows && k < cols)
-      v = g[m + (long) k * ld];
-    img[k * C::LD + m] = re_of(v);
-    if constexpr (C::CX)
-      img[C::IMG + k * C::LD + m] = im_of(v);
-  }
+  T regs[kCoopPerThread];
+  coop_fetch<T>(regs, g, ld, rows, cols);
+  coop_commit<T>(img, regs);
 }
 
 // acc(m = wave*16 + c, n = j*16 + irow(g, v)) = sum_k A[m][k] * conj(B[n][k]) over the 64 x 64 images
@@ -126,7 +173,7 @@ __device__ __forceinline__ void coop_mma64(const real_t<T>* A, const real_t<T>* 
 }
 
 template <class T>
-__global__ __launch_bounds__(kThreads, 1) void potrf_coop_kernel(T* __restrict__ tile, int ld, int kb,
+__global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__ tile, int ld, int kb,
                                                                   T* __restrict__ winv, int* info, int info_base,
                                                                   unsigned* sync) {
   using C = CoopCfg<T>;
@@ -173,38 +220,59 @@ __global__ __launch_bounds__(kThreads, 1) void potrf_coop_kernel(T* __restrict__
         if constexpr (C::CX)
           Aimg[C::IMG + n * C::LD + m] = xim[jt][v];
         if (m < rows_s)
-          Asj[m + (long) n * ld] = make_el<T>(xre[jt][v], C::CX ? xim[jt][v] : R(0));
+          store_wt(&Asj[m + (long) n * ld], make_el<T>(xre[jt][v], C::CX ? xim[jt][v] : R(0)));
       }
     coop_publish(&cnt[j], 1u, true);
     const unsigned arrived = coop_wait(&cnt[j], (unsigned) (G - 1 - j), &wait_slot);
     if (arrived == 0xFFFFFFFFu)
       return;
     // ---- A(s,c) -= X_s * X_c^H for c = j+1 .. s ----------------------------------------------------
+    // the C block (and, for real types, X_{c+1}) is fetched while the MFMAs of block c run; complex
+    // types have no registers to spare for the X prefetch beside a co-resident bulk-update wave
+    constexpr bool kPrefetch = !C::CX;
+    T nextB[kPrefetch ? kCoopPerThread : 1];
+    if constexpr (kPrefetch)
+      coop_fetch<T>(nextB, tile + (long) kCB * (j + 1) + (long) kCB * j * ld, ld, min(kCB, kb - kCB * (j + 1)), jb);
     for (int cc = j + 1; cc <= s; ++cc) {
       const int rows_c = min(kCB, kb - kCB * cc);
-      coop_load_image<T>(Bimg, tile + (long) kCB * cc + (long) kCB * j * ld, ld, rows_c, jb);
+      if constexpr (kPrefetch)
+        coop_commit<T>(Bimg, nextB);
+      else
+        coop_load_image<T>(Bimg, tile + (long) kCB * cc + (long) kCB * j * ld, ld, rows_c, jb);
       __syncthreads();
-      acc_t ure[4], uim[4];
-      coop_mma64<T>(Aimg, Bimg, ure, uim);
+      if constexpr (kPrefetch)
+        if (cc + 1 <= s)
+          coop_fetch<T>(nextB, tile + (long) kCB * (cc + 1) + (long) kCB * j * ld, ld, min(kCB, kb - kCB * (cc + 1)),
+                        jb);
       T* Csc = tile + (long) kCB * s + (long) kCB * cc * ld;
       const bool diag = (cc == s);
+      T cv[4][4];
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int m = wave * 16 + c, n = jt * 16 + Mma<R>::irow(g, v);
+          cv[jt][v] = (m < rows_s && n < rows_c && (!diag || m >= n)) ? Csc[m + (long) n * ld] : zero_el<T>();
+        }
+      acc_t ure[4], uim[4];
+      coop_mma64<T>(Aimg, Bimg, ure, uim);
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int m = wave * 16 + c, n = jt * 16 + Mma<R>::irow(g, v);
           if (m < rows_s && n < rows_c && (!diag || m >= n)) {
-            T cv = Csc[m + (long) n * ld];
+            T r = cv[jt][v];
             if constexpr (C::CX) {
-              cv = T{cv.re - ure[jt][v], (diag && m == n) ? R(0) : cv.im - uim[jt][v]};
+              r = T{r.re - ure[jt][v], (diag && m == n) ? R(0) : r.im - uim[jt][v]};
             }
             else {
-              cv = cv - ure[jt][v];
+              r = r - ure[jt][v];
             }
-            Csc[m + (long) n * ld] = cv;
+            Csc[m + (long) n * ld] = r;
           }
         }
-      __syncthreads();  // B image is reloaded by the next iteration
+      __syncthreads();  // B image is rewritten by the next iteration
     }
     // my own stores to block (s, .) must be visible to my own later loads: same CU, ordered by the
     // barrier above; the next step's first action is a wait on flag[j+1] anyway
@@ -223,22 +291,28 @@ __global__ __launch_bounds__(kThreads, 1) void potrf_coop_kernel(T* __restrict__
     // make sure my own updates of block (s,s) (plain stores of this workgroup) are complete
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int idx = t; idx < kPD * kPD; idx += kThreads) {
-      const int r = idx % kPD, cl = idx / kPD;
-      R re = 0, imv = 0;
-      if (r < jb && cl < jb && r >= cl) {
-        const T v = Ass[r + (long) cl * ld];
-        re = re_of(v);
-        imv = im_of(v);
+    {
+      T regs[kCoopPerThread];
+#pragma unroll
+      for (int q = 0; q < kCoopPerThread; ++q) {
+        const int idx = t + q * kThreads;
+        const int r = idx % kPD, cl = idx / kPD;
+        regs[q] = (r < jb && cl < jb && r >= cl) ? Ass[r + (long) cl * ld] : zero_el<T>();
       }
-      if (r == cl && r >= jb)
-        re = 1;
-      Lre[cl * kPDLd + r] = re;
-      if constexpr (C::CX)
-        Lim[cl * kPDLd + r] = (r == cl) ? R(0) : imv;
-      Wre[cl * kPDLd + r] = 0;
-      if constexpr (C::CX)
-        Wim[cl * kPDLd + r] = 0;
+#pragma unroll
+      for (int q = 0; q < kCoopPerThread; ++q) {
+        const int idx = t + q * kThreads;
+        const int r = idx % kPD, cl = idx / kPD;
+        R re = re_of(regs[q]), imv = im_of(regs[q]);
+        if (r == cl && r >= jb)
+          re = 1;
+        Lre[cl * kPDLd + r] = re;
+        if constexpr (C::CX)
+          Lim[cl * kPDLd + r] = (r == cl) ? R(0) : imv;
+        Wre[cl * kPDLd + r] = 0;
+        if constexpr (C::CX)
+          Wim[cl * kPDLd + r] = 0;
+      }
     }
     __syncthreads();
     const int failed = diag_factor_invert<T>(Lre, Lim, Wre, Wim, jb, 1, &fail_col);
@@ -263,7 +337,7 @@ __global__ __launch_bounds__(kThreads, 1) void potrf_coop_kernel(T* __restrict__
         if constexpr (C::CX)
           wim = Wim[cl * kPDLd + rr];
       }
-      Ws[rr + (long) cl * kPD] = make_el<T>(wre, wim);
+      store_wt(&Ws[rr + (long) cl * kPD], make_el<T>(wre, wim));
     }
     coop_publish(&flag[s], 1u, false);
   }
