@@ -34,14 +34,18 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=3)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--n", type=int, default=65536)
-    p.add_argument("--nb", type=int, default=1024)
+    # --matrix-size / --block-size as in the reference miniapp (miniapp_cholesky.cpp:223-224);
+    # the short forms are for single-process use (torchrun's own parser trips over "--n")
+    p.add_argument("--matrix-size", "--n", dest="n", type=int, default=65536)
+    p.add_argument("--block-size", "--nb", dest="nb", type=int, default=1024)
     p.add_argument("--type", default="d", choices=["s", "d", "c", "z"])
     p.add_argument("--uplo", default="L", choices=["L", "U"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-n", type=int, default=8192)
     p.add_argument("--cpu-nb", type=int, default=256)
     p.add_argument("--check", action="store_true", help="download and check the residual of the last run (N <= 16384)")
+    p.add_argument("--transport", default="rccl", choices=["rccl", "host"],
+                   help="host = gloo-staged broadcasts: lets several ranks rehearse the N > 1 path on ONE GPU")
     return p.parse_args()
 
 
@@ -63,6 +67,24 @@ def cpu_baseline(args):
                       f"register-blocked C tile kernels), {dt:.2f} s wall"}
 
 
+def host_grid(dlaf, dist, torch, nprow, npcol):
+    """Column-major grid whose broadcasts go through gloo (rehearsal transport)."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    myrow, mycol = rank % nprow, rank // nprow
+    rank_of = lambda r, c: c * nprow + r  # noqa: E731
+    rows = [dist.new_group([rank_of(r, c) for c in range(npcol)]) for r in range(nprow)]
+    cols = [dist.new_group([rank_of(r, c) for r in range(nprow)]) for c in range(npcol)]
+
+    def bcast(axis, root, buf):
+        t = torch.frombuffer(buf, dtype=torch.uint8)
+        if axis == 0:
+            dist.broadcast(t, src=rank_of(myrow, root), group=rows[myrow])
+        else:
+            dist.broadcast(t, src=rank_of(root, mycol), group=cols[mycol])
+
+    return dlaf.Grid.host(world, rank, nprow, npcol, "C", bcast, dist.barrier)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -77,14 +99,23 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: dla_future_amd has no CPU path")
-    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    ndev = torch.cuda.device_count()
+    torch.cuda.set_device(local_rank % ndev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank % torch.cuda.device_count()))
+        if args.transport == "rccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank % ndev))
+        else:
+            dist.init_process_group("gloo")
 
     import dla_future_amd as dlaf
     dlaf.initialize()
     nprow, npcol = GRIDS.get(world, (1, world))
-    grid = dlaf.Grid.from_torch(nprow, npcol, "C") if world > 1 else dlaf.Grid.single()
+    if world == 1:
+        grid = dlaf.Grid.single()
+    elif args.transport == "rccl":
+        grid = dlaf.Grid.from_torch(nprow, npcol, "C")
+    else:
+        grid = host_grid(dlaf, dist, torch, nprow, npcol)
 
     n, nb = args.n, args.nb
     dt = {"s": np.float32, "d": np.float64, "c": np.complex64, "z": np.complex128}[args.type]
@@ -136,7 +167,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.transport == "rccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -162,7 +193,8 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": {"s": "f32", "d": "f64", "c": "c64", "z": "c128"}[args.type],
             "data": "synthetic",
             "config": {"workload": f"cholesky_{args.type} N={n} nb={nb} uplo={args.uplo}", "grid": f"{nprow}x{npcol}",
-                       "rank_order": "column-major", "work_copies": npool,
+                       "rank_order": "column-major", "transport": args.transport if world > 1 else "none",
+                       "work_copies": npool,
                        "restore_in_timed_region": bool(args.steps > npool)},
             "fraction_of_fp64_mfma_peak": round(tflops / (world * PEAK_FP64_MFMA_TFLOPS), 4),
             "roofline": {"kernel": "update_kernel<T,VEC,0> (grouped trailing herk+gemm)", "bound": "mfma",

@@ -18,9 +18,7 @@ namespace dlaf_mi355x {
 template <class T>
 struct TrsmCfg {
   using type = BlockCfg<T, 128, kDiagBlock, 32, kDiagBlock, 16>;
-  // Y and X accumulators are live together in the second product: give the allocator the whole
-  // 512-register file (1 wave/SIMD) instead of spilling at 256
-  static constexpr int min_waves = 1;
+  static constexpr int min_waves = 2;
 };
 template <>
 struct TrsmCfg<cdouble> {
@@ -28,10 +26,18 @@ struct TrsmCfg<cdouble> {
   static constexpr int min_waves = 1;
 };
 
+template <class T>
+constexpr int trsm_lds_bytes() {
+  using Cfg = typename TrsmCfg<T>::type;
+  constexpr int w = (TypeInfo<T>::is_complex ? 2 : 1) * kDiagBlock * (kDiagBlock + kLdsPad) * (int) sizeof(real_t<T>);
+  return Cfg::LDS_BYTES > w ? Cfg::LDS_BYTES : w;
+}
+
 template <class T, bool VEC>
 __global__ __launch_bounds__(kThreads, TrsmCfg<T>::min_waves) void trsm_kernel(TrsmArgs<T> p, int spt) {
   using Cfg = typename TrsmCfg<T>::type;
   using R = real_t<T>;
+  using acc_t = typename Mma<R>::acc_t;
   constexpr int JB = kDiagBlock;
   static_assert(Cfg::BN == JB && Cfg::WAVES_N == 1, "a wave must own whole rows of the strip");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -84,56 +90,49 @@ __global__ __launch_bounds__(kThreads, TrsmCfg<T>::min_waves) void trsm_kernel(T
         }
       }
 
-    // ---- X = Y * W_j^H, W_j = inv(L_jj) staged through LDS in BK-wide k chunks ----------------
-    Acc<Cfg> x;
-    x.clear();
+    // ---- X = Y * W_j^H: W_j = inv(L_jj) staged whole into LDS, X produced and stored one 16-column
+    // tile at a time (highest first: Y tile ct only feeds X tiles j2 >= ct) so that Y and a single X
+    // tile column are all that is live in registers
     const T* Wj = p.winv + (long) j * JB * JB;
-    Slab<T, JB, Cfg::BK, true> sw;  // winv blocks are dense 64x64, 16-byte aligned
-    R* Ws = lds;                    // [k][JB + pad] (+ im plane)
     constexpr int LDW = JB + kLdsPad;
-    constexpr int WPLANE = Cfg::BK * LDW;
-#pragma unroll
-    for (int kc = 0; kc < JB / Cfg::BK; ++kc) {
-      sw.template load<false>(Wj, JB, kc * Cfg::BK, JB, JB);
+    constexpr int WPLANE = JB * LDW;
+    R* Ws = lds;  // [k][JB + pad] (+ im plane)
+    {
+      Slab<T, JB, JB, true, LDW> sw;  // winv blocks are dense 64x64, 16-byte aligned
+      sw.template load<false>(Wj, JB, 0, JB, JB);
       sw.store(Ws);
-      __syncthreads();
-      constexpr int kTilesPerChunk = (Cfg::BK >= 16) ? Cfg::BK / 16 : 1;
-      static_assert(Cfg::BK == 16 || Cfg::BK == 8, "chunk must be one or half a 16-wide k tile");
-      const int ct = (kc * Cfg::BK) / 16;  // k tile (16 wide) this chunk belongs to (static after unrolling)
-      (void) kTilesPerChunk;
+    }
+    __syncthreads();
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        // accumulator register v of lane-group g holds k = 16*ct + irow(g, v).  With BK == 8 (f64
-        // only: irow = g + 4v) registers {0,1} live in the first half chunk and {2,3} in the second.
-        if (Cfg::BK == 8 && (v >> 1) != (kc & 1))
-          continue;
-        const int kloc = 16 * ct + Mma<R>::irow(g, v) - kc * Cfg::BK;
+    for (int j2 = Cfg::TN - 1; j2 >= 0; --j2) {
+      acc_t xre[Cfg::TM], xim[Cfg::TM];
 #pragma unroll
-        for (int j2 = 0; j2 < Cfg::TN; ++j2) {
-          if (j2 < ct)
-            continue;  // W is lower triangular: W[n2][k] = 0 for k > n2
-          const R w_re = Ws[kloc * LDW + j2 * 16 + c];
+      for (int i = 0; i < Cfg::TM; ++i) {
+        xre[i] = acc_t{0, 0, 0, 0};
+        xim[i] = acc_t{0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int ct = 0; ct <= j2; ++ct)  // W is lower triangular: W[n2][k] = 0 for k > n2
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          // accumulator register v of lane-group g holds k = 16*ct + irow(g, v): read the partner
+          // fragment of W at exactly that k ("accumulator as next operand")
+          const int kabs = 16 * ct + Mma<R>::irow(g, v);
+          const R w_re = Ws[kabs * LDW + j2 * 16 + c];
           R w_im = R(0);
           if constexpr (Cfg::CX)
-            w_im = Ws[WPLANE + kloc * LDW + j2 * 16 + c];
+            w_im = Ws[WPLANE + kabs * LDW + j2 * 16 + c];
 #pragma unroll
           for (int i = 0; i < Cfg::TM; ++i) {
-            x.re[i][j2] = Mma<R>::mma(w_re, y.re[i][ct][v], x.re[i][j2]);
+            xre[i] = Mma<R>::mma(w_re, y.re[i][ct][v], xre[i]);
             if constexpr (Cfg::CX) {
               // (yr + i yi)(wr - i wi) = (yr wr + yi wi) + i (yi wr - yr wi)
-              x.re[i][j2] = Mma<R>::mma(w_im, y.im[i][ct][v], x.re[i][j2]);
-              x.im[i][j2] = Mma<R>::mma(w_re, y.im[i][ct][v], x.im[i][j2]);
-              x.im[i][j2] = Mma<R>::mma(-w_im, y.re[i][ct][v], x.im[i][j2]);
+              xre[i] = Mma<R>::mma(w_im, y.im[i][ct][v], xre[i]);
+              xim[i] = Mma<R>::mma(w_re, y.im[i][ct][v], xim[i]);
+              xim[i] = Mma<R>::mma(-w_im, y.re[i][ct][v], xim[i]);
             }
           }
         }
-      }
-      __syncthreads();
-    }
-
-    // ---- store X_j ------------------------------------------------------------------------------
-#pragma unroll
-    for (int j2 = 0; j2 < Cfg::TN; ++j2)
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int nl = j2 * 16 + Mma<R>::irow(g, v);
@@ -142,12 +141,13 @@ __global__ __launch_bounds__(kThreads, TrsmCfg<T>::min_waves) void trsm_kernel(T
           const int ml = wm * Cfg::WM + i * 16 + c;
           if (full || (ml < mrows && nl < jb)) {
             if constexpr (Cfg::CX)
-              Bj[ml + (long) nl * p.ldb] = T{x.re[i][j2][v], x.im[i][j2][v]};
+              Bj[ml + (long) nl * p.ldb] = T{xre[i][v], xim[i][v]};
             else
-              Bj[ml + (long) nl * p.ldb] = x.re[i][j2][v];
+              Bj[ml + (long) nl * p.ldb] = xre[i][v];
           }
         }
       }
+    }
     // X_j is read back (through L1/L2) by this workgroup's next K loop
     __syncthreads();
   }
@@ -167,18 +167,18 @@ void launch_trsm(const TrsmArgs<T>& a, hipStream_t stream) {
   const long grid = (long) (a.il1 - a.il0) * spt;
   const bool vec = aligned16<T>(a.b, a.ldb) && aligned16<T>(a.b, a.b_ts) && aligned16<T>(a.l, a.ldl);
   if (vec)
-    hipLaunchKernelGGL((trsm_kernel<T, true>), dim3((unsigned) grid), dim3(kThreads), Cfg::LDS_BYTES, stream, a, spt);
+    hipLaunchKernelGGL((trsm_kernel<T, true>), dim3((unsigned) grid), dim3(kThreads), trsm_lds_bytes<T>(), stream, a, spt);
   else
-    hipLaunchKernelGGL((trsm_kernel<T, false>), dim3((unsigned) grid), dim3(kThreads), Cfg::LDS_BYTES, stream, a, spt);
+    hipLaunchKernelGGL((trsm_kernel<T, false>), dim3((unsigned) grid), dim3(kThreads), trsm_lds_bytes<T>(), stream, a, spt);
 }
 
 template <class T>
 static void trsm_init_one() {
-  using Cfg = typename TrsmCfg<T>::type;
+
   (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_kernel<T, true>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+                             hipFuncAttributeMaxDynamicSharedMemorySize, trsm_lds_bytes<T>());
   (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_kernel<T, false>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+                             hipFuncAttributeMaxDynamicSharedMemorySize, trsm_lds_bytes<T>());
 }
 
 void trsm_kernels_init() {
