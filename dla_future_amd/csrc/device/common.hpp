@@ -119,7 +119,8 @@ constexpr int kLdsPad = 16;    // elements of padding per k-row of an LDS panel 
 // Global image: column-major, element (r, k) at src[r + k*ld].  LDS image: [k][ROWS+pad]
 // (k-major, rows contiguous), one plane for real types, re/im planes for complex.
 // VEC: 16-byte loads (needs src 16-B aligned, ld*sizeof(T) % 16 == 0); otherwise per element.
-template <class T, int ROWS, int BK, bool VEC, int LD_ = ROWS + kLdsPad>
+// IL (complex only): re/im interleaved in LDS ([k][LD] of (re, im) pairs) instead of two planes.
+template <class T, int ROWS, int BK, bool VEC, int LD_ = ROWS + kLdsPad, bool IL = false>
 struct Slab {
   using R = real_t<T>;
   static constexpr bool CX = TypeInfo<T>::is_complex;
@@ -170,12 +171,22 @@ struct Slab {
       const int idx = t + kThreads * q;
       const int r = (idx % (ROWS / VE)) * VE;
       const int k = idx / (ROWS / VE);
-      R* d = lds + k * LD + r;
+      if constexpr (IL) {
+        R* d = lds + 2 * (k * LD + r);
 #pragma unroll
-      for (int e = 0; e < VE; ++e) {
-        d[e] = re_of(regs[q][e]);
-        if constexpr (CX)
-          d[PLANE + e] = im_of(regs[q][e]);
+        for (int e = 0; e < VE; ++e) {
+          d[2 * e] = re_of(regs[q][e]);
+          d[2 * e + 1] = im_of(regs[q][e]);
+        }
+      }
+      else {
+        R* d = lds + k * LD + r;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          d[e] = re_of(regs[q][e]);
+          if constexpr (CX)
+            d[PLANE + e] = im_of(regs[q][e]);
+        }
       }
     }
   }

@@ -24,12 +24,16 @@ struct BlockCfg {
   static constexpr int WAVES_M = BM / WM, WAVES_N = BN / WN;
   static_assert(WAVES_M * WAVES_N * 64 == kThreads, "4 waves per workgroup");
   static_assert(BK % 4 == 0 && WM % 16 == 0 && WN % 16 == 0, "MFMA 16x16x4 granularity");
-  static constexpr bool PAIRED = PAIRED_;
-  static_assert(!PAIRED || (!CX && TM % 2 == 0 && TN % 2 == 0), "paired rows: real types, even tile counts");
-  static constexpr int PAD = PAIRED ? 0 : kLdsPad;
+  // For complex types PAIRED_ selects the interleaved LDS image instead ([k][ROWS] of (re, im)): one
+  // ds_read_b128 per fragment and, with 64-row granularity, direct-to-LDS staging of 16-byte elements.
+  static constexpr bool PAIRED = PAIRED_ && !CX;
+  static constexpr bool CXI = PAIRED_ && CX;
+  static_assert(!PAIRED || (TM % 2 == 0 && TN % 2 == 0), "paired rows: even tile counts");
+  static constexpr int PAD = PAIRED_ ? 0 : kLdsPad;
   static constexpr int LDA = BM + PAD, LDB = BN + PAD;
   // direct-to-LDS staging: one wave instruction (64 lanes x 16 B) must be exactly one slab column
-  static constexpr bool GLDS = PAIRED && sizeof(T) * BM == 1024 && sizeof(T) * BN == 1024 && (BK % 4 == 0);
+  static constexpr bool GLDS = (PAIRED && sizeof(T) * BM == 1024 && sizeof(T) * BN == 1024 && (BK % 4 == 0)) ||
+                               (CXI && sizeof(T) == 16 && BM % 64 == 0 && BN % 64 == 0);
   static constexpr int A_PLANE = BK * LDA, B_PLANE = BK * LDB;
   static constexpr int A_ELEMS = (CX ? 2 : 1) * A_PLANE, B_ELEMS = (CX ? 2 : 1) * B_PLANE;
   static constexpr int BUF_ELEMS = A_ELEMS + B_ELEMS;
@@ -68,7 +72,22 @@ __device__ __forceinline__ void mma_slab(const typename Cfg::R* __restrict__ As,
   for (int k4 = 0; k4 < Cfg::BK / 4; ++k4) {
     const int kk = k4 * 4 + g;
     R a_re[Cfg::TM], a_im[Cfg::TM], b_re[Cfg::TN], b_im[Cfg::TN];
-    if constexpr (Cfg::PAIRED) {
+    if constexpr (Cfg::CXI) {
+      typedef R r2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int i = 0; i < Cfg::TM; ++i) {
+        const r2 v = *reinterpret_cast<const r2*>(&As[2 * (kk * Cfg::LDA + wm * Cfg::WM + i * 16 + c)]);
+        a_re[i] = v[0];
+        a_im[i] = v[1];
+      }
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j) {
+        const r2 v = *reinterpret_cast<const r2*>(&Bs[2 * (kk * Cfg::LDB + wn * Cfg::WN + j * 16 + c)]);
+        b_re[j] = v[0];
+        b_im[j] = v[1];
+      }
+    }
+    else if constexpr (Cfg::PAIRED) {
       typedef R r2 __attribute__((ext_vector_type(2)));
 #pragma unroll
       for (int q = 0; q < Cfg::TM / 2; ++q) {
@@ -136,6 +155,29 @@ __device__ __forceinline__ int acc_n(int j, int g, int v) {
 template <class Cfg, class T>
 __device__ __forceinline__ void stage_glds(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb, int k0,
                                            typename Cfg::R* __restrict__ buf, int wave, int lane) {
+  if constexpr (Cfg::CXI) {
+    // 16-byte elements: one instruction moves 64 rows of one column; wave w takes every 4th piece
+    constexpr int PA = Cfg::BM / 64, PB = Cfg::BN / 64;
+#pragma unroll
+    for (int idx = 0; idx < (Cfg::BK * PA) / 4; ++idx) {
+      const int piece = wave + 4 * idx;
+      const int k = piece / PA, part = piece % PA;
+      const T* ga = A + part * 64 + lane + (long) (k0 + k) * lda;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) ga,
+                                       (__attribute__((address_space(3))) void*) (buf + 2 * (k * Cfg::LDA + part * 64)),
+                                       16, 0, 0);
+    }
+#pragma unroll
+    for (int idx = 0; idx < (Cfg::BK * PB) / 4; ++idx) {
+      const int piece = wave + 4 * idx;
+      const int k = piece / PB, part = piece % PB;
+      const T* gb = B + part * 64 + lane + (long) (k0 + k) * ldb;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*) gb,
+          (__attribute__((address_space(3))) void*) (buf + Cfg::A_ELEMS + 2 * (k * Cfg::LDB + part * 64)), 16, 0, 0);
+    }
+    return;
+  }
   constexpr int PER = 16 / (int) sizeof(T);  // elements per lane
 #pragma unroll
   for (int q = 0; q < Cfg::BK / 4; ++q) {
@@ -169,7 +211,7 @@ __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda,
     // consumed.  Each wave issues LPS loads per slab; "vmcnt(LPS*(STAGES-2))" therefore means "my share
     // of slab kt+1 has landed", and the raw barrier extends that to every wave's share.
     constexpr int ST = Cfg::STAGES;
-    constexpr int LPS = 2 * (Cfg::BK / 4);
+    constexpr int LPS = Cfg::CXI ? (Cfg::BK * (Cfg::BM / 64) + Cfg::BK * (Cfg::BN / 64)) / 4 : 2 * (Cfg::BK / 4);
 #pragma unroll
     for (int s = 0; s < ST - 1; ++s)
       if (s < nk)
@@ -203,8 +245,8 @@ __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda,
     }
     return;
   }
-  Slab<T, Cfg::BM, Cfg::BK, VEC, Cfg::LDA> sa;
-  Slab<T, Cfg::BN, Cfg::BK, VEC, Cfg::LDB> sb;
+  Slab<T, Cfg::BM, Cfg::BK, VEC, Cfg::LDA, Cfg::CXI> sa;
+  Slab<T, Cfg::BN, Cfg::BK, VEC, Cfg::LDB, Cfg::CXI> sb;
   sa.template load<EDGE>(A, lda, 0, mrows, K);
   sb.template load<EDGE>(B, ldb, 0, ncols, K);
   sa.store(lds);

@@ -10,6 +10,10 @@
 #include <vector>
 
 using namespace dlaf_mi355x;
+#ifndef UB_TYPE
+#define UB_TYPE double
+#endif
+using TT = UB_TYPE;
 
 int main(int argc, char** argv) {
   const int nt = argc > 1 ? atoi(argv[1]) : 24;
@@ -17,18 +21,19 @@ int main(int argc, char** argv) {
   const int reps = argc > 3 ? atoi(argv[3]) : 3;
   const long max_blocks = argc > 4 ? atol(argv[4]) : 0;  // > 0: persistent grid of that many workgroups
   update_kernels_init();
+  printf("resident workgroups per CU (occupancy API): %d\n", update_blocks_per_cu<TT>());
   const size_t te = (size_t) nb * nb;
-  double* tiles;
+  TT* tiles;
   int* info;
-  (void) hipMalloc(&tiles, sizeof(double) * te * nt * nt);
+  (void) hipMalloc(&tiles, sizeof(TT) * te * nt * nt);
   (void) hipMalloc(&info, sizeof(int));
   (void) hipMemset(info, 0, sizeof(int));
-  std::vector<double> h(te * nt);
+  std::vector<double> h(te * nt * (sizeof(TT) / sizeof(double) > 0 ? sizeof(TT) / sizeof(double) : 1));
   srand(1);
   for (auto& v : h) v = (rand() / (double) RAND_MAX) * 2 - 1;
   for (int j = 0; j < nt; ++j)
-    (void) hipMemcpy(tiles + te * nt * j, h.data(), sizeof(double) * te * nt, hipMemcpyHostToDevice);
-  UpdateArgs<double> ua;
+    (void) hipMemcpy(tiles + te * nt * j, h.data(), sizeof(TT) * te * nt, hipMemcpyHostToDevice);
+  UpdateArgs<TT> ua;
   ua.c = tiles;
   ua.c_tsr = (long) te;
   ua.c_tsc = (long) te * nt;
@@ -49,7 +54,8 @@ int main(int argc, char** argv) {
   ua.last_rows = nb;
   ua.info = info;
   const double t = nt - 1;
-  const double flops = t * (t - 1) / 2 * 2.0 * nb * nb * nb + t * (double) nb * (nb + 1) * nb;
+  const double cxf = TypeInfo<TT>::is_complex ? 4.0 : 1.0;
+  const double flops = cxf * (t * (t - 1) / 2 * 2.0 * nb * nb * nb + t * (double) nb * (nb + 1) * nb);
   hipEvent_t e0, e1;
   (void) hipEventCreate(&e0);
   (void) hipEventCreate(&e1);
