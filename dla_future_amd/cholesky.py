@@ -200,6 +200,15 @@ class DeviceMatrix:
     def wait(self) -> int:
         return lib().dlaf_mi355x_cholesky_wait(self._h)
 
+    def residual_against(self, factor: "DeviceMatrix"):
+        """check_cholesky of the miniapp (miniapp_cholesky.cpp:408-443) on the device.  `self` must hold the
+        ORIGINAL matrix and is overwritten with A - L L^H.  Returns (max|A - L L^H|, max|A|) over the grid."""
+        d, a = C.c_double(), C.c_double()
+        r = lib().dlaf_mi355x_cholesky_residual(self._h, factor._h, C.byref(d), C.byref(a))
+        if r != 0:
+            raise ValueError("matrices are not conformable")
+        return d.value, a.value
+
     PROFILE_KINDS = {"update_bulk": 0, "update_lookahead": 1, "trsm_panel": 2, "potrf_tile": 3}
 
     def profile(self, kind: str) -> dict:

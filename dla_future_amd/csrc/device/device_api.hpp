@@ -115,6 +115,14 @@ template <class T>
 void launch_copy2d(T* dst, long ldd, const T* src, long lds, int rows, int cols, int transpose, int mask,
                    hipStream_t stream);
 
+// checker helpers: max |a_ij| over the lower triangle of the local tiles (into *out, device double) and
+// zeroing of the strict upper part of the local diagonal tiles
+template <class T>
+void launch_max_norm(const T* tiles, int ltr, int ltc, int nb, long rows, long cols, int pr, int ri, int pc, int ci,
+                     double* out, hipStream_t stream);
+template <class T>
+void launch_zero_upper_diag(T* tiles, int ltr, int ltc, int nb, int pr, int ri, int pc, int ci, hipStream_t stream);
+
 // one-off: opt the kernels into > 64 KiB of dynamic LDS
 void device_kernels_init();
 

@@ -118,6 +118,87 @@ void launch_copy2d(T* dst, long ldd, const T* src, long lds, int rows, int cols,
                      mask);
 }
 
+// ---- checker helpers (miniapp/miniapp_cholesky.cpp:243-259 setUpperToZeroForDiagonalTiles,
+// include/dlaf/auxiliary/norm/mc.h max_norm) -------------------------------------------------------
+// one workgroup per local tile: max |a_ij| over the tiles with global row >= global column (lower part of
+// diagonal tiles), folded into *out (non-negative doubles order like their bit patterns)
+template <class T>
+__global__ __launch_bounds__(kThreads) void max_norm_kernel(const T* tiles, int ltr, int nb, long rows, long cols,
+                                                            int pr, int ri, int pc, int ci,
+                                                            unsigned long long* out) {
+  __shared__ double red[kThreads];
+  const int il = blockIdx.x, jl = blockIdx.y;
+  const int gi = il * pr + ri, gj = jl * pc + ci;
+  double m = 0;
+  if (gi >= gj) {
+    const int rt = (int) min((long) nb, rows - (long) il * nb), ct = (int) min((long) nb, cols - (long) jl * nb);
+    const T* t = tiles + ((long) il + (long) jl * ltr) * nb * nb;
+    for (long idx = threadIdx.x; idx < (long) rt * ct; idx += kThreads) {
+      const int r = (int) (idx % rt), c = (int) (idx / rt);
+      if (gi > gj || r >= c) {
+        const T v = t[r + (long) c * nb];
+        const double a = TypeInfo<T>::is_complex ? hypot((double) re_of(v), (double) im_of(v)) : fabs((double) re_of(v));
+        m = a > m ? a : m;  // NaN never wins a comparison; report it explicitly
+        if (a != a)
+          m = a;
+      }
+    }
+  }
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      const double o = red[threadIdx.x + s];
+      if (o > red[threadIdx.x] || o != o)
+        red[threadIdx.x] = o;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double v = red[0];
+    if (v != v)
+      v = 1e300;  // NaN -> "infinite" residual
+    atomicMax(out, (unsigned long long) __double_as_longlong(v));
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(kThreads) void zero_upper_diag_kernel(T* tiles, int ltr, int ltc, int nb, int pr, int ri,
+                                                                    int pc, int ci) {
+  const int il = blockIdx.x;
+  // the local column that holds the diagonal tile of local row il, if any
+  const int gi = il * pr + ri;
+  if ((gi - ci) % pc != 0 || gi < ci)
+    return;
+  const int jl = (gi - ci) / pc;
+  if (jl >= ltc)
+    return;
+  T* t = tiles + ((long) il + (long) jl * ltr) * nb * nb;
+  for (long idx = threadIdx.x; idx < (long) nb * nb; idx += kThreads) {
+    const int r = (int) (idx % nb), c = (int) (idx / nb);
+    if (r < c)
+      t[r + (long) c * nb] = zero_el<T>();
+  }
+}
+
+template <class T>
+void launch_max_norm(const T* tiles, int ltr, int ltc, int nb, long rows, long cols, int pr, int ri, int pc, int ci,
+                     double* out, hipStream_t stream) {
+  (void) hipMemsetAsync(out, 0, sizeof(double), stream);
+  if (ltr <= 0 || ltc <= 0)
+    return;
+  hipLaunchKernelGGL((max_norm_kernel<T>), dim3((unsigned) ltr, (unsigned) ltc), dim3(kThreads), 0, stream, tiles, ltr, nb,
+                     rows, cols, pr, ri, pc, ci, reinterpret_cast<unsigned long long*>(out));
+}
+
+template <class T>
+void launch_zero_upper_diag(T* tiles, int ltr, int ltc, int nb, int pr, int ri, int pc, int ci, hipStream_t stream) {
+  if (ltr <= 0 || ltc <= 0)
+    return;
+  hipLaunchKernelGGL((zero_upper_diag_kernel<T>), dim3((unsigned) ltr), dim3(kThreads), 0, stream, tiles, ltr, ltc, nb, pr,
+                     ri, pc, ci);
+}
+
 void update_kernels_init();
 void trsm_kernels_init();
 void potrf_kernels_init();
@@ -133,7 +214,9 @@ void device_kernels_init() {
 #define INST(T)                                                                \
   template void launch_to_tiles<T>(const LayoutArgs<T>&, hipStream_t);         \
   template void launch_from_tiles<T>(const LayoutArgs<T>&, hipStream_t);     \
-  template void launch_copy2d<T>(T*, long, const T*, long, int, int, int, int, hipStream_t);
+  template void launch_copy2d<T>(T*, long, const T*, long, int, int, int, int, hipStream_t);    \
+  template void launch_max_norm<T>(const T*, int, int, int, long, long, int, int, int, int, double*, hipStream_t); \
+  template void launch_zero_upper_diag<T>(T*, int, int, int, int, int, int, int, hipStream_t);
 INST(float)
 INST(double)
 INST(cfloat)

@@ -353,6 +353,13 @@ int dlaf_mi355x_cholesky_factorization_device(dlaf_mi355x_matrix_t h) noexcept {
   WITH_MATRIX(h, return M.factorize();)
 }
 
+int dlaf_mi355x_cholesky_residual(dlaf_mi355x_matrix_t original, dlaf_mi355x_matrix_t factor, double* max_diff,
+                                  double* max_a) noexcept {
+  if (!original || !factor || original->type != factor->type)
+    return -1;
+  WITH_MATRIX(original, M.residual_of(static_cast<DeviceMatrix<DT>&>(*factor->m), max_diff, max_a); return 0;)
+}
+
 int dlaf_mi355x_matrix_profile(dlaf_mi355x_matrix_t h, int kind, double* ms, long* launches, double* flops,
                                double* bytes) noexcept {
   if (kind < 0 || kind > 3)

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <exception>
 
@@ -77,6 +78,24 @@ public:
     DLAF_HIP_CHECK(hipStreamSynchronize(stream));
     if (barrier_ && barrier_(user_) != 0)
       fatal("[dlaf_mi355x] host barrier callback failed\n");
+  }
+  void allreduce_max(double* v, int n, int nprow, int npcol, int myrow, int mycol) override {
+    // with only row/column broadcasts at hand: every member of my row broadcasts in turn, then every
+    // member of my column
+    std::vector<double> tmp((size_t) n);
+    for (int pass = 0; pass < 2; ++pass) {
+      const int members = pass == 0 ? npcol : nprow, me = pass == 0 ? mycol : myrow;
+      std::vector<double> best(v, v + n);
+      for (int root = 0; root < members; ++root) {
+        if (me == root)
+          std::copy(v, v + n, tmp.begin());
+        if (bcast_(user_, pass, root, tmp.data(), sizeof(double) * (size_t) n) != 0)
+          fatal("[dlaf_mi355x] host broadcast callback failed\n");
+        for (int i = 0; i < n; ++i)
+          best[(size_t) i] = std::max(best[(size_t) i], tmp[(size_t) i]);
+      }
+      std::copy(best.begin(), best.end(), v);
+    }
   }
 
 private:
@@ -696,6 +715,112 @@ void DeviceMatrix<T>::factorize_async() {
   DLAF_HIP_CHECK(hipEventRecord(ev_low[0], s_main));
   DLAF_HIP_CHECK(hipStreamWaitEvent(s_panel, ev_low[0], 0));
   DLAF_HIP_CHECK(hipMemcpyAsync(info_host, info, sizeof(int), hipMemcpyDeviceToHost, s_panel));
+}
+
+// ------------------------------------------------------------------------------- residual checker
+// max|A - L L^H| / max|A| as the reference's miniapp computes it (miniapp_cholesky.cpp:243-443:
+// setUpperToZeroForDiagonalTiles, cholesky_diff with row/column broadcasts + reduce, max_norm), on the
+// device: the same grouped update kernel subtracts L(:,k) L(:,k)^H column panel by column panel, the
+// panels travel exactly like in the factorization, the norms are reduced over the grid with MAX.
+template <class T>
+void DeviceMatrix<T>::residual_of(DeviceMatrix<T>& L, double* max_diff, double* max_a) {
+  if (L.n != n || L.nb != nb || L.ltr != ltr || L.ltc != ltc || L.transposed != transposed)
+    fatal("[dlaf_mi355x] residual_of: matrices differ in shape or distribution\n");
+  Transport* tr = grid->transport.get();
+  const bool dist = grid->nranks > 1;
+  const CommAxis ax_row = transposed ? CommAxis::Col : CommAxis::Row;
+  const CommAxis ax_col = transposed ? CommAxis::Row : CommAxis::Col;
+  const size_t tile_bytes = tile_elems * sizeof(T);
+  hipStream_t s = s_low;
+  double* dnorm = nullptr;
+  DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dnorm), 2 * sizeof(double)));
+  DLAF_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int), s));
+  launch_max_norm(tiles, (int) ltr, (int) ltc, nb, rows.local_size(), cols.local_size(), rows.P, rows.shift(), cols.P,
+                  cols.shift(), dnorm + 1, s);
+  launch_zero_upper_diag(L.tiles, (int) ltr, (int) ltc, nb, rows.P, rows.shift(), cols.P, cols.shift(), s);
+  DLAF_HIP_CHECK(hipStreamSynchronize(s));
+  for (long k = 0; k < nt; ++k) {
+    const int kb = rows.tile_extent(k);
+    const int own_c = cols.owner(k);
+    const bool in_col = cols.rank == own_c;
+    const long il_f = rows.next_local(k), jl_f = cols.next_local(k);
+    const long klc = in_col ? cols.local_of(k) : -1;
+    if (il_f >= ltr && !dist)
+      continue;
+    const T* a_base;
+    const T* b_base;
+    long b_ts = (long) tile_elems;
+    if (cols.P > 1) {
+      T* dst = in_col ? L.tile(il_f < ltr ? il_f : 0, klc) : panel[0];
+      if (il_f < ltr)
+        tr->bcast(ax_row, own_c, cols.rank, dst, dst, (size_t) (ltr - il_f) * tile_bytes, s);
+      a_base = dst;
+    }
+    else {
+      a_base = L.tile(il_f < ltr ? il_f : 0, klc);
+    }
+    if (rows.P > 1) {
+      tr->group_begin();
+      for (long jl = jl_f; jl < ltc; ++jl) {
+        const long gj = cols.global_of(jl);
+        if (gj == nt - 1 && gj != k)
+          continue;
+        const int root_r = rows.owner(gj);
+        const T* src = (rows.rank == root_r) ? a_base + (size_t) (rows.local_of(gj) - il_f) * tile_elems : nullptr;
+        tr->bcast(ax_col, root_r, rows.rank, src, panelT[0] + (size_t) (jl - jl_f) * tile_elems, tile_bytes, s);
+      }
+      tr->group_end();
+      b_base = panelT[0];
+    }
+    else {
+      b_base = a_base + (cols.global_of(jl_f) - il_f) * (long) tile_elems;
+      b_ts = (long) tile_elems * cols.P;
+    }
+    if (il_f >= ltr || jl_f >= ltc)
+      continue;
+    const long il0 = std::max(il_f, rows.next_local(cols.global_of(jl_f)));
+    if (il0 >= ltr)
+      continue;
+    UpdateArgs<T> ua;
+    ua.c = tiles;
+    ua.c_tsr = (long) tile_elems;
+    ua.c_tsc = (long) (tile_elems * ltr);
+    ua.ldc = nb;
+    ua.a = a_base + (size_t) (il0 - il_f) * tile_elems;
+    ua.a_ts = (long) tile_elems;
+    ua.lda = nb;
+    ua.b = b_base;
+    ua.b_ts = b_ts;
+    ua.ldb = nb;
+    ua.il0 = (int) il0;
+    ua.il1 = (int) ltr;
+    ua.jl0 = (int) jl_f;
+    ua.jl1 = (int) ltc;
+    ua.nb = nb;
+    ua.K = kb;
+    ua.pr = rows.P;
+    ua.ri = rows.shift();
+    ua.pc = cols.P;
+    ua.ci = cols.shift();
+    ua.nt = (int) nt;
+    ua.last_rows = rows.last_extent();
+    ua.info = info;
+    launch_update(ua, s, 0);
+    if (dist)
+      DLAF_HIP_CHECK(hipStreamSynchronize(s));  // the single panel workspace is reused by the next step
+  }
+  launch_max_norm(tiles, (int) ltr, (int) ltc, nb, rows.local_size(), cols.local_size(), rows.P, rows.shift(), cols.P,
+                  cols.shift(), dnorm, s);
+  DLAF_HIP_CHECK(hipStreamSynchronize(s));
+  double h[2];
+  DLAF_HIP_CHECK(hipMemcpy(h, dnorm, sizeof(h), hipMemcpyDeviceToHost));
+  DLAF_HIP_CHECK(hipFree(dnorm));
+  if (dist)
+    tr->allreduce_max(h, 2, grid->nprow, grid->npcol, grid->myrow, grid->mycol);
+  if (max_diff)
+    *max_diff = h[0];
+  if (max_a)
+    *max_a = h[1];
 }
 
 template <class T>

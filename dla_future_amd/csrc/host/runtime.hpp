@@ -50,6 +50,9 @@ public:
   virtual void group_begin() {}
   virtual void group_end() {}
   virtual void barrier(hipStream_t stream) = 0;
+  // max over every rank of the grid of n host doubles (the reference's sync::reduce with MPI_MAX in
+  // max_norm, include/dlaf/auxiliary/norm/mc.h); result on every rank
+  virtual void allreduce_max(double* host_vals, int n, int nprow, int npcol, int myrow, int mycol) = 0;
 };
 
 struct Grid {
@@ -127,6 +130,9 @@ struct DeviceMatrix : MatrixBase {
   void upload(const T* host, long ld);     // caller's local column-major array -> tiles
   void download(T* host, long ld);         // tiles -> caller's array (uplo triangle only)
   void copy_from(const DeviceMatrix<T>& other);
+  // Checker (miniapp/miniapp_cholesky.cpp:408-443): `this` holds the ORIGINAL matrix and is overwritten
+  // with A - L L^H on the uplo triangle; returns max|A - L L^H| and max|A| over the whole grid.
+  void residual_of(DeviceMatrix<T>& factor, double* max_diff, double* max_a);
   int factorize();                         // blocking; returns LAPACK-style info
   void factorize_async();                  // enqueue only
   int wait();                              // drain + info

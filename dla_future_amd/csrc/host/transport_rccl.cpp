@@ -58,6 +58,15 @@ public:
     DLAF_NCCL_CHECK(ncclAllReduce(token_, token_, 1, ncclInt, ncclSum, world_, stream));
     DLAF_HIP_CHECK(hipStreamSynchronize(stream));
   }
+  void allreduce_max(double* host_vals, int n, int, int, int, int) override {
+    double* d = nullptr;
+    DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d), sizeof(double) * n));
+    DLAF_HIP_CHECK(hipMemcpy(d, host_vals, sizeof(double) * n, hipMemcpyHostToDevice));
+    DLAF_NCCL_CHECK(ncclAllReduce(d, d, n, ncclDouble, ncclMax, world_, nullptr));
+    DLAF_HIP_CHECK(hipStreamSynchronize(nullptr));
+    DLAF_HIP_CHECK(hipMemcpy(host_vals, d, sizeof(double) * n, hipMemcpyDeviceToHost));
+    DLAF_HIP_CHECK(hipFree(d));
+  }
 
 private:
   ncclComm_t world_ = nullptr, row_ = nullptr, col_ = nullptr;

@@ -62,6 +62,13 @@ DLAF_EXTERN_C int dlaf_mi355x_matrix_copy(dlaf_mi355x_matrix_t dst, dlaf_mi355x_
 DLAF_EXTERN_C int dlaf_mi355x_cholesky_start(dlaf_mi355x_matrix_t m) DLAF_NOEXCEPT;
 DLAF_EXTERN_C int dlaf_mi355x_cholesky_wait(dlaf_mi355x_matrix_t m) DLAF_NOEXCEPT;
 DLAF_EXTERN_C int dlaf_mi355x_cholesky_factorization_device(dlaf_mi355x_matrix_t m) DLAF_NOEXCEPT;
+/* Residual checker of the miniapp (miniapp/miniapp_cholesky.cpp:408-443 check_cholesky with
+ * auxiliary/norm max_norm) on the device: `original` holds the input matrix and is OVERWRITTEN with
+ * A - L L^H (uplo triangle); *max_diff = max|A - L L^H|, *max_a = max|A| over the whole grid (MAX-reduced
+ * through the grid's transport).  The strict upper part of the factor's diagonal tiles is zeroed on the
+ * device (it is never written back to the caller).  Collective. */
+DLAF_EXTERN_C int dlaf_mi355x_cholesky_residual(dlaf_mi355x_matrix_t original, dlaf_mi355x_matrix_t factor,
+                                                double* max_diff, double* max_a) DLAF_NOEXCEPT;
 /* Live timing of the last factorization, measured with HIP events on the stream each launch class
  * runs on.  kind 0: grouped trailing update (herk+gemm of columns > k+1), 1: lookahead-column update,
  * 2: panel TRSM, 3: diagonal-tile POTRF chain.  ms = summed launch durations, flops / bytes = summed

@@ -108,6 +108,31 @@ def main():
                     print(f"[dist_worker] FAILED case {t}{uplo} n={n} nb={nb} grid {nprow}x{npcol}: max diff {md}", flush=True)
                 ok &= good
             ok &= bool((store[rows:, :] == 7.5).all())
+        # device-side residual checker with the MAX reduction over the grid (miniapp check_cholesky)
+        for t, uplo, n, nb in [("d", "L", 200, 32), ("z", "U", 90, 16)]:
+            dt = oracle.DTYPES[t]
+            sr, sc = 0, 0
+            rows, cols = grid.local_shape(n, nb, sr, sc)
+            loc = np.zeros((max(1, rows), max(1, cols)), dtype=dt, order="F")[:rows, :cols]
+            dlaf.set_random_hermitian_positive_definite(grid, loc, n, nb, sr, sc)
+            a0 = gather_global(loc, grid, n, nb, sr, sc, oracle)
+            orig = dlaf.DeviceMatrix(grid, dt, uplo, n, nb, sr, sc)
+            fact = dlaf.DeviceMatrix(grid, dt, uplo, n, nb, sr, sc)
+            orig.upload(loc)
+            fact.copy_from(orig)
+            ok &= fact.factorize() == 0
+            fact.download(loc)
+            got = gather_global(loc, grid, n, nb, sr, sc, oracle)
+            diff, norm_a = orig.residual_against(fact)
+            host = oracle.cholesky_residual(uplo, a0, got)
+            eps = oracle.eps_of(dt)
+            good = abs(norm_a - np.abs(oracle.tri(uplo, a0)).max()) <= 1e-6 * norm_a
+            good &= diff / norm_a <= n * eps and abs(diff / norm_a - host) <= 8 * eps
+            if not good and rank == 0:
+                print(f"[dist_worker] residual check FAILED {t}{uplo}: device {diff / norm_a} host {host}", flush=True)
+            ok &= bool(good)
+            orig.close()
+            fact.close()
         # analytic known-answer matrix through the ScaLAPACK-style entry (test_cholesky_c_api.cpp:108-155)
         n, nb = 34, 13
         a, l = oracle.cholesky_setters("L", n, np.float64)

@@ -130,3 +130,52 @@ def test_larger_property_checks(dlaf, grid, oracle, t):
     assert (np.diag(a).real > 0).all() and (np.diag(a).imag == 0).all()
     assert np.array_equal(np.triu(a, 1), np.triu(a0, 1))
     assert oracle.cholesky_residual("L", a0, a) <= n * oracle.eps_of(dt)
+
+
+@pytest.mark.parametrize("t", ["d", "z", "s"])
+@pytest.mark.parametrize("uplo", ["L", "U"])
+def test_device_residual_checker_matches_host(dlaf, grid, oracle, t, uplo):
+    """dlaf_mi355x_cholesky_residual (the miniapp's check_cholesky on the device) against the same
+    quantity computed on the host from the downloaded factor."""
+    n, nb = 700, 128
+    dt = oracle.DTYPES[t]
+    a0 = oracle.set_random_hpd(n, nb, dt)
+    orig = dlaf.DeviceMatrix(grid, dt, uplo, n, nb)
+    fact = dlaf.DeviceMatrix(grid, dt, uplo, n, nb)
+    orig.upload(a0)
+    fact.copy_from(orig)
+    assert fact.factorize() == 0
+    out = a0.copy(order="F")
+    fact.download(out)
+    diff, norm_a = orig.residual_against(fact)
+    tri0 = oracle.tri(uplo, a0)
+    assert norm_a == pytest.approx(np.abs(tri0).max(), rel=1e-6)
+    host = oracle.cholesky_residual(uplo, a0, out)
+    eps = oracle.eps_of(dt)
+    assert diff / norm_a <= n * eps                      # miniapp bar (miniapp_cholesky.cpp:432-442)
+    assert abs(diff / norm_a - host) <= 8 * eps          # same quantity up to summation order
+    # a wrong factor must be flagged
+    bad = out.copy(order="F")
+    idx = (n // 2, n // 3) if uplo == "L" else (n // 3, n // 2)
+    bad[idx] += dt(0.5)
+    fact.upload(bad)
+    orig.upload(a0)
+    diff2, _ = orig.residual_against(fact)
+    assert diff2 / norm_a > 100 * n * eps
+
+
+def test_full_size_residual_on_device(dlaf, grid, oracle):
+    """Property check at a size the host checker cannot reach: N = 16384, nb = 1024 (the headline tile
+    size), residual computed entirely on the GPU."""
+    n, nb = 16384, 1024
+    a = np.zeros((n, n), dtype=np.float64, order="F")
+    dlaf.set_random_hermitian_positive_definite(grid, a, n, nb)
+    orig = dlaf.DeviceMatrix(grid, np.float64, "L", n, nb)
+    fact = dlaf.DeviceMatrix(grid, np.float64, "L", n, nb)
+    orig.upload(a)
+    del a
+    fact.copy_from(orig)
+    assert fact.factorize() == 0
+    diff, norm_a = orig.residual_against(fact)
+    assert norm_a > 2 * n - 1.001 and norm_a < 2 * n + 1.001
+    assert diff / norm_a <= n * np.finfo(np.float64).eps
