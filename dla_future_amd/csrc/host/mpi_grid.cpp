@@ -1,0 +1,95 @@
+// mpi_grid.cpp -- the MPI-typed grid entry points of the reference's C API, built into the optional
+// libdlaf_mi355x_mpi.so (only when mpi.h / libmpi exist at build time; the core library stays MPI-free).
+//
+//   dlaf_create_grid(MPI_Comm, nprow, npcol, order)     include/dlaf_c/grid.h:31, src/c_api/grid.cpp:28-39
+//   grid_ordering(MPI_Comm, nprow, npcol, myprow, mypcol)  include/dlaf_c/grid.h:54, src/c_api/grid.cpp:45-68
+//
+// MPI is used for what the reference uses it for at this point -- the barrier and the process
+// layout -- plus the bootstrap of the device transport:
+//   DLAF_MI355X_MPI_TRANSPORT=rccl (default): rank 0's RCCL unique id is MPI_Bcast to the grid, the
+//       factorization then talks RCCL over xGMI only;
+//   DLAF_MI355X_MPI_TRANSPORT=host: panel broadcasts are staged through host memory and sent with MPI_Bcast
+//       on row / column communicators from MPI_Comm_split -- the reference's non-GPU-aware-MPI path
+//       (communication/kernels/internal/broadcast.h:62-70); lets several ranks share one GPU.
+#define DLAF_MI355X_WITH_MPI 1
+#include <mpi.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+
+#include <dlaf_c/grid.h>
+#include <dlaf_mi355x/dlaf_mi355x.h>
+
+namespace {
+struct MpiComms {
+  MPI_Comm world = MPI_COMM_NULL, row = MPI_COMM_NULL, col = MPI_COMM_NULL;
+};
+std::map<int, std::unique_ptr<MpiComms>> g_comms;  // kept alive as long as the grid
+
+int host_bcast(void* user, int axis, int root, void* buf, size_t bytes) {
+  auto* c = static_cast<MpiComms*>(user);
+  MPI_Comm comm = axis == 0 ? c->row : c->col;
+  size_t off = 0;
+  while (off < bytes) {  // MPI counts are ints
+    const int chunk = (int) std::min<size_t>(bytes - off, (size_t) 1 << 30);
+    if (MPI_Bcast(static_cast<char*>(buf) + off, chunk, MPI_BYTE, root, comm) != MPI_SUCCESS)
+      return 1;
+    off += (size_t) chunk;
+  }
+  return 0;
+}
+
+int host_barrier(void* user) {
+  return MPI_Barrier(static_cast<MpiComms*>(user)->world) == MPI_SUCCESS ? 0 : 1;
+}
+}  // namespace
+
+extern "C" int dlaf_create_grid(MPI_Comm comm, int nprow, int npcol, char order) noexcept {
+  int rank = 0, size = 1;
+  MPI_Barrier(comm);  // reference: grid.cpp:35
+  MPI_Comm_rank(comm, &rank);
+  MPI_Comm_size(comm, &size);
+  if (nprow * npcol != size) {
+    std::fprintf(stderr, "[dlaf_mi355x] dlaf_create_grid: %d x %d grid on a communicator of %d ranks\n", nprow, npcol,
+                 size);
+    std::abort();
+  }
+  if (size == 1)
+    return dlaf_mi355x_create_grid_single();
+  const char* tr = std::getenv("DLAF_MI355X_MPI_TRANSPORT");
+  if (tr && std::strcmp(tr, "host") == 0) {
+    auto c = std::make_unique<MpiComms>();
+    const bool colmajor = (order == 'C' || order == 'c');
+    const int myrow = colmajor ? rank % nprow : rank / npcol;
+    const int mycol = colmajor ? rank / nprow : rank % npcol;
+    MPI_Comm_dup(comm, &c->world);
+    // row communicator ranked by process column, column communicator ranked by process row
+    // (src/communication/communicator_grid.cpp:41-43)
+    MPI_Comm_split(comm, myrow, mycol, &c->row);
+    MPI_Comm_split(comm, mycol, myrow, &c->col);
+    const int ctx = dlaf_mi355x_create_grid_host(size, rank, nprow, npcol, order, host_bcast, host_barrier, c.get());
+    g_comms[ctx] = std::move(c);
+    return ctx;
+  }
+  char uid[DLAF_MI355X_UNIQUE_ID_BYTES];
+  if (rank == 0)
+    dlaf_mi355x_rccl_unique_id(uid);
+  MPI_Bcast(uid, DLAF_MI355X_UNIQUE_ID_BYTES, MPI_BYTE, 0, comm);
+  return dlaf_mi355x_create_grid_rccl(uid, size, rank, nprow, npcol, order);
+}
+
+extern "C" char grid_ordering(MPI_Comm comm, int nprow, int npcol, int myprow, int mypcol) noexcept {
+  int rank = 0;
+  MPI_Comm_rank(comm, &rank);
+  int mine[2] = {rank == myprow * npcol + mypcol ? 1 : 0, rank == mypcol * nprow + myprow ? 1 : 0};
+  int all[2] = {0, 0};
+  MPI_Allreduce(mine, all, 2, MPI_INT, MPI_LAND, comm);
+  if (!all[0] && !all[1]) {
+    std::fprintf(stderr, "Grid layout must be row major or column major.\n");
+    std::exit(-1);
+  }
+  return all[1] ? 'C' : 'R';
+}
