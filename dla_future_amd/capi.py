@@ -66,6 +66,7 @@ SIGNATURES = {
     "dlaf_mi355x_grid_host_bcast": (_i, [_i, _i, _i, _vp, C.c_size_t]),
     "dlaf_mi355x_grid_info": (_i, [_i, _IP, _IP, _IP, _IP]),
     "dlaf_mi355x_grid_barrier": (_i, [_i]),
+    "dlaf_mi355x_grid_selftest": (_i, [_i, C.c_size_t]),
     "dlaf_mi355x_matrix_create": (_i, [_i, _ch, _ch, DLAFDescriptor, C.POINTER(_vp)]),
     "dlaf_mi355x_matrix_destroy": (None, [_vp]),
     "dlaf_mi355x_matrix_upload": (_i, [_vp, _vp, _i]),

@@ -115,6 +115,10 @@ class Grid:
     def barrier(self) -> None:
         lib().dlaf_mi355x_grid_barrier(self.context)
 
+    def selftest(self, nbytes: int = 1 << 20) -> int:
+        """Collective wiring check of the row / column communicators; number of failed checks (0 = good)."""
+        return int(lib().dlaf_mi355x_grid_selftest(self.context, nbytes))
+
     def free(self) -> None:
         """dlaf_free_grid (include/dlaf_c/grid.h:39)."""
         if self.context >= 0:

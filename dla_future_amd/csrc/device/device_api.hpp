@@ -10,6 +10,9 @@ namespace dlaf_mi355x {
 
 // Block size of the diagonal factorization / inverted diagonal blocks used by the TRSM.
 constexpr int kDiagBlock = 64;
+// *info value stored by a kernel whose bounded inter-workgroup wait expired (workgroups of the cooperative
+// POTRF not co-scheduled): a runtime failure, never a property of the matrix; the host aborts on it.
+constexpr int kInfoSchedulingFailure = -1000000;
 
 // ------------------------------------------------------------------------------------------
 // Trailing update (tile::herk + tile::gemm of a whole step in ONE launch):

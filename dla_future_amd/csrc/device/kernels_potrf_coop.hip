@@ -200,8 +200,12 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
   for (int j = 0; j < s; ++j) {
     const int jb = kCB;  // every block column left of my diagonal block is full
     const unsigned f = coop_wait(&flag[j], 1u, &wait_slot);
-    if (f != 1u)
-      return;  // not positive definite (info already set by the owner) or spin bound hit
+    if (f != 1u) {
+      // not positive definite (info already set by the owner), or the spin bound was hit
+      if (f == 0xFFFFFFFFu && t == 0)
+        atomicCAS(info, 0, kInfoSchedulingFailure);
+      return;
+    }
     // ---- X_s = A(s,j) * inv(L_jj)^H ----------------------------------------------------------------
     T* Asj = tile + (long) kCB * s + (long) kCB * j * ld;
     coop_load_image<T>(Aimg, Asj, ld, rows_s, jb);
@@ -224,8 +228,11 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
       }
     coop_publish(&cnt[j], 1u, true);
     const unsigned arrived = coop_wait(&cnt[j], (unsigned) (G - 1 - j), &wait_slot);
-    if (arrived == 0xFFFFFFFFu)
+    if (arrived == 0xFFFFFFFFu) {
+      if (t == 0)
+        atomicCAS(info, 0, kInfoSchedulingFailure);
       return;
+    }
     // ---- A(s,c) -= X_s * X_c^H for c = j+1 .. s ----------------------------------------------------
     // the C block (and, for real types, X_{c+1}) is fetched while the MFMAs of block c run; complex
     // types have no registers to spare for the X prefetch beside a co-resident bulk-update wave

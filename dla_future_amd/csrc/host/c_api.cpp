@@ -5,6 +5,7 @@
 #include <climits>
 #include <complex>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <unordered_map>
@@ -231,7 +232,10 @@ int dlaf_mi355x_create_grid_rccl(const void* uid, int nranks, int rank, int npro
   if (!g)
     return -1;
   runtime_init();
-  if (nranks > 1)
+  // a 1-process grid needs no communicator; DLAF_MI355X_RCCL_SINGLE=1 creates them anyway (communicator
+  // init / split / teardown exercised on a one-GPU box)
+  const char* force = std::getenv("DLAF_MI355X_RCCL_SINGLE");
+  if (nranks > 1 || (force && force[0] == '1'))
     g->transport = make_rccl_transport(uid, nranks, rank, nprow, npcol, g->myrow, g->mycol);
   return register_grid(std::move(g));
 }
@@ -274,6 +278,13 @@ int dlaf_mi355x_grid_barrier(int ctx) noexcept {
   else if (runtime_initialized())
     (void) hipDeviceSynchronize();
   return 0;
+}
+
+int dlaf_mi355x_grid_selftest(int ctx, size_t bytes) noexcept {
+  auto it = g_grids.find(ctx);
+  if (it == g_grids.end())
+    return -1;
+  return grid_selftest(*it->second, bytes);
 }
 
 int dlaf_mi355x_grid_host_bcast(int ctx, int axis, int root, void* host_buf, size_t bytes) noexcept {

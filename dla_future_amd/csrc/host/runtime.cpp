@@ -717,6 +717,70 @@ void DeviceMatrix<T>::factorize_async() {
   DLAF_HIP_CHECK(hipMemcpyAsync(info_host, info, sizeof(int), hipMemcpyDeviceToHost, s_panel));
 }
 
+// ------------------------------------------------------------------------------- grid self-test
+int grid_selftest(Grid& g, size_t bytes) {
+  runtime_init();
+  if (g.nranks > 1 && !g.transport && g.host_bcast)
+    g.transport = make_host_transport(g.host_bcast, g.host_barrier, g.host_user);
+  Transport* tr = g.transport.get();
+  if (!tr)
+    return 0;  // 1x1 grid without communicators
+  const size_t words = std::max<size_t>(1, bytes / sizeof(unsigned));
+  unsigned *src = nullptr, *dst = nullptr;
+  DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&src), words * sizeof(unsigned)));
+  DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dst), 2 * words * sizeof(unsigned)));
+  std::vector<unsigned> h(words), back(2 * words);
+  hipStream_t s = nullptr;
+  DLAF_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  int bad = 0;
+  auto pattern = [&](int axis, int root, int fixed, int form, size_t i) {
+    return (unsigned) (0x9E3779B1u * (unsigned) (i + 1)) ^ (unsigned) (axis << 28 | form << 24 | root << 12 | fixed);
+  };
+  for (int axis = 0; axis < 2; ++axis) {
+    const CommAxis ax = axis == 0 ? CommAxis::Row : CommAxis::Col;
+    const int members = axis == 0 ? g.npcol : g.nprow;
+    const int me = axis == 0 ? g.mycol : g.myrow;
+    const int fixed = axis == 0 ? g.myrow : g.mycol;
+    for (int root = 0; root < members; ++root) {
+      // form 0: in place;  form 1: out of place;  form 2: two grouped out-of-place broadcasts
+      for (int form = 0; form < 3; ++form) {
+        for (size_t i = 0; i < words; ++i)
+          h[i] = (me == root) ? pattern(axis, root, fixed, form, i) : 0xDEADBEEFu;
+        DLAF_HIP_CHECK(hipMemcpyAsync(src, h.data(), words * sizeof(unsigned), hipMemcpyHostToDevice, s));
+        DLAF_HIP_CHECK(hipMemsetAsync(dst, 0, 2 * words * sizeof(unsigned), s));
+        const void* send = (me == root) ? src : nullptr;
+        if (form == 0)
+          tr->bcast(ax, root, me, src, src, words * sizeof(unsigned), s);
+        else if (form == 1)
+          tr->bcast(ax, root, me, send, dst, words * sizeof(unsigned), s);
+        else {
+          tr->group_begin();
+          tr->bcast(ax, root, me, send, dst, words * sizeof(unsigned), s);
+          tr->bcast(ax, root, me, send, dst + words, words * sizeof(unsigned), s);
+          tr->group_end();
+        }
+        DLAF_HIP_CHECK(hipMemcpyAsync(back.data(), form == 0 ? src : dst, (form == 2 ? 2 : 1) * words * sizeof(unsigned),
+                                      hipMemcpyDeviceToHost, s));
+        DLAF_HIP_CHECK(hipStreamSynchronize(s));
+        for (size_t i = 0; i < (form == 2 ? 2 : 1) * words; ++i)
+          if (back[i] != pattern(axis, root, fixed, form, i % words)) {
+            ++bad;
+            break;
+          }
+      }
+    }
+  }
+  tr->barrier(s);
+  double v[2] = {(double) (g.myrow * g.npcol + g.mycol), -(double) (g.myrow * g.npcol + g.mycol)};
+  tr->allreduce_max(v, 2, g.nprow, g.npcol, g.myrow, g.mycol);
+  if (v[0] != (double) (g.nprow * g.npcol - 1) || v[1] != 0.0)
+    ++bad;
+  DLAF_HIP_CHECK(hipStreamDestroy(s));
+  (void) hipFree(src);
+  (void) hipFree(dst);
+  return bad;
+}
+
 // ------------------------------------------------------------------------------- residual checker
 // max|A - L L^H| / max|A| as the reference's miniapp computes it (miniapp_cholesky.cpp:243-443:
 // setUpperToZeroForDiagonalTiles, cholesky_diff with row/column broadcasts + reduce, max_norm), on the
@@ -829,6 +893,9 @@ int DeviceMatrix<T>::wait() {
   DLAF_HIP_CHECK(hipStreamSynchronize(s_low));
   DLAF_HIP_CHECK(hipStreamSynchronize(s_high));
   DLAF_HIP_CHECK(hipMemcpy(info_host, info, sizeof(int), hipMemcpyDeviceToHost));
+  if (*info_host == kInfoSchedulingFailure)
+    fatal("[dlaf_mi355x] cooperative POTRF: a bounded inter-workgroup wait expired (workgroups not co-resident); "
+          "the result is invalid. DLAF_MI355X_POTRF=chain selects the non-cooperative path.\n");
   for (auto& ps : prof) {
     ps.ms = 0;
     ps.launches = (long) ps.used;
@@ -891,6 +958,8 @@ int tile_potrf(char uplo, int n, T* a, int lda) {
   int h = 0;
   DLAF_HIP_CHECK(hipMemcpyAsync(&h, info.p, sizeof(int), hipMemcpyDeviceToHost, s));
   DLAF_HIP_CHECK(hipStreamSynchronize(s));
+  if (h == kInfoSchedulingFailure)
+    fatal("[dlaf_mi355x] cooperative POTRF: a bounded inter-workgroup wait expired; the result is invalid\n");
   return h;
 }
 

@@ -148,6 +148,11 @@ void tile_herk(char uplo, int n, int k, const T* a, int lda, T* c, int ldc);
 template <class T>
 void tile_gemm(char uplo, int m, int n, int k, const T* a, int lda, const T* b, int ldb, T* c, int ldc);
 
+// Communication self-test of a grid: every member of every row / column communicator broadcasts a
+// coordinate-dependent pattern in turn (in place, out of place and grouped, the three forms the
+// factorization issues), then barrier + max-allreduce.  Returns the number of mismatching checks.
+int grid_selftest(Grid& g, size_t bytes);
+
 void runtime_init();
 void runtime_finalize();
 bool runtime_initialized();

@@ -77,6 +77,12 @@ DLAF_EXTERN_C int dlaf_mi355x_matrix_profile(dlaf_mi355x_matrix_t m, int kind, d
                                              double* flops, double* bytes) DLAF_NOEXCEPT;
 /* barrier over the matrix's grid (RCCL all-reduce / host callback) */
 DLAF_EXTERN_C int dlaf_mi355x_grid_barrier(int context) DLAF_NOEXCEPT;
+/* Collective communication self-test of a grid (what test/unit/communication/test_broadcast*.cpp do for
+ * the reference's MPI layer): every member of every row / column communicator broadcasts `bytes` of a
+ * coordinate-dependent pattern in place, out of place and grouped, then barrier + max-allreduce.
+ * Returns the number of failed checks on this process (0 = good), -1 for an unknown context.
+ * DLAF_MI355X_RCCL_SINGLE=1 makes create_grid_rccl build communicators for a 1-process grid too. */
+DLAF_EXTERN_C int dlaf_mi355x_grid_selftest(int context, size_t bytes) DLAF_NOEXCEPT;
 
 /* ---- synthetic input ------------------------------------------------------------------------ */
 /* Fills this process's local array (column-major, ld) of the n x n matrix with the reference's

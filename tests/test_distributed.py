@@ -58,3 +58,42 @@ def test_grid_wiring_and_generation_gloo_cpu(nprow, npcol, order):
 @pytest.mark.parametrize("nprow,npcol,order", [(1, 2, "R"), (2, 1, "R"), (2, 2, "C"), (3, 2, "R"), (2, 3, "C")])
 def test_distributed_cholesky_one_gpu_many_ranks(nprow, npcol, order):
     launch("gpu", nprow, npcol, order, timeout=600)
+
+
+RCCL_SINGLE = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import dla_future_amd as dlaf
+from oracle import oracle
+dlaf.initialize()
+g = dlaf.Grid.rccl(dlaf.Grid.rccl_unique_id(), 1, 0, 1, 1, "R")
+assert g.selftest(1 << 20) == 0
+g.barrier()
+n, nb = 300, 64
+a = oracle.set_random_hpd(n, nb, np.float64)
+got = a.copy(order="F")
+assert dlaf.cholesky_factorization(g, "L", got, nb) == 0
+ref = a.copy(order="F")
+assert oracle.cholesky_local("L", ref, nb) == 0
+tol = 4 * (n + 1) * 2 * oracle.eps_of(np.float64)
+assert oracle.check_near(np.tril(ref), np.tril(got), tol, tol)[0]
+orig = dlaf.DeviceMatrix(g, np.float64, "L", n, nb); fact = dlaf.DeviceMatrix(g, np.float64, "L", n, nb)
+orig.upload(a); fact.copy_from(orig)
+assert fact.factorize() == 0
+diff, norm_a = orig.residual_against(fact)      # ncclAllReduce(ncclMax) leg of the checker
+assert diff / norm_a <= n * oracle.eps_of(np.float64)
+orig.close(); fact.close(); g.free(); dlaf.finalize()
+print("RCCL_SINGLE OK")
+"""
+
+
+@pytest.mark.gpu
+def test_rccl_communicators_on_a_one_process_grid():
+    """What a one-GPU box can exercise of the RCCL transport: unique id, ncclCommInitRank, the two
+    ncclCommSplit sub-communicators, in-place / out-of-place / grouped ncclBroadcast, the all-reduce
+    barrier and the ncclMax reduction, and communicator teardown (the multi-rank call sequence is the
+    one the host-transport tests above verify through the same Transport interface)."""
+    env = dict(os.environ, DLAF_MI355X_RCCL_SINGLE="1", DLAF_MI355X_DEVICE="0")
+    r = subprocess.run([sys.executable, "-c", RCCL_SINGLE % ROOT], cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "RCCL_SINGLE OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
