@@ -157,10 +157,10 @@ void DeviceMatrix<T>::create(Grid* g, char uplo_, long n_, int nb_, int isrc, in
   tile_elems = (size_t) nb * nb;
 
   tiles = dev_alloc<T>((size_t) ltr * ltc * tile_elems);
-  winv = dev_alloc<T>(winv_elems());
+  winv = dev_alloc<T>(2 * winv_elems());  // alternating by step parity
   const bool dist = g->nranks > 1;
   if (dist) {
-    diag_ws = dev_alloc<T>(tile_elems + winv_elems());
+    diag_ws = dev_alloc<T>(2 * (tile_elems + winv_elems()));  // alternating by step parity
     for (int b = 0; b < 2; ++b) {
       panel[b] = dev_alloc<T>((size_t) ltr * tile_elems);
       panelT[b] = dev_alloc<T>((size_t) ltc * tile_elems);
@@ -214,6 +214,8 @@ void DeviceMatrix<T>::create(Grid* g, char uplo_, long n_, int nb_, int isrc, in
   ev_high = make_events(ne);
   ev_diag = make_events(ne);
   ev_bcast = make_events(ne);
+  ev_head = make_events(ne);
+  ev_headb = make_events(ne);
   ev_bcastT = make_events(2);
 }
 
@@ -222,7 +224,7 @@ void DeviceMatrix<T>::destroy() {
   if (!tiles)
     return;
   (void) hipDeviceSynchronize();
-  for (auto* v : {&ev_panel, &ev_low, &ev_high, &ev_diag, &ev_bcast, &ev_bcastT}) {
+  for (auto* v : {&ev_panel, &ev_low, &ev_high, &ev_diag, &ev_bcast, &ev_bcastT, &ev_head, &ev_headb}) {
     for (auto e : *v)
       (void) hipEventDestroy(e);
     v->clear();
@@ -433,19 +435,29 @@ static void potrf_tile(T* t, int ld, int kb, T* winv, int* info, int info_base, 
 // ------------------------------------------------------------------------------- the tile DAG
 // Right-looking Cholesky (cholesky/impl.h:150-189 local, :192-313 distributed) of the lower
 // triangle of the view.  Three in-order streams; events carry the RAW/WAR edges the reference gets
-// from per-tile async_rw_mutex.  Stream order on s_main for step k (U(k, J) = trailing update of
-// tile columns J with panel k):
+// from per-tile async_rw_mutex.  U(k, J) = trailing update of tile columns J with panel k.
+//
+// "classic" schedule (one process):
 //
 //   s_main : U(k-1, col k) . U(k-1, rest_A) . TRSM(k) . U(k-1, rest_B) . U(k, col k+1) . U(k, rest_A) ...
-//   s_panel:                  POTRF(k)  [diag bcast]                      POTRF(k+1)
-//   s_comm :                                          panel(k) / panelT(k) broadcasts
+//   s_panel:                  POTRF(k)                                     POTRF(k+1)
 //
-// i.e. the narrow, latency-bound POTRF chain of the NEXT diagonal tile runs beside the first slice
-// (rest_A) of the current bulk update on compute units kept out of s_main's CU mask, the wide
-// kernels never compete with each other, and the panel broadcasts of step k fly under rest_B of step
-// k-1.  This is the reference's lookahead rule (high priority for potrf/trsm and for trailing column
-// k+1, impl.h:172-173 / :280-281) expressed as an explicit order, because on this GPU a
-// high-priority stream's kernels do not pre-empt the queued workgroups of a running bulk kernel.
+// the narrow, latency-bound POTRF of the NEXT diagonal tile runs beside the first slice (rest_A) of the
+// current bulk update in workgroup slots that slice leaves free.  This is the reference's lookahead rule
+// (high priority for potrf/trsm and for trailing column k+1, impl.h:172-173 / :280-281) expressed as an
+// explicit order, because on this GPU a high-priority stream's kernels do not pre-empt the queued
+// workgroups of a running bulk kernel.
+//
+// "early diagonal" schedule (process grids; DLAF_MI355X_SCHEDULE=early|classic overrides): with
+// broadcasts in the loop the per-step chain POTRF -> bcast -> TRSM -> bcast -> U(col k+1) -> POTRF is
+// what bounds a multi-GPU run, so the diagonal tile leaves that chain.  The lookahead is two columns
+// deep, the panel's first tile ("head": A(k+1,k), the only operand D(k+1) needs) is solved and
+// broadcast ahead of the rest, and D(k+1) is updated and factored on s_panel while the panel of step k
+// is still on the wire:
+//
+//   s_main : TRSMhead(k) . TRSMtail(k) . U(k-1, cols >= k+2) . U(k, cols {k+1,k+2} below D(k+1)) . TRSMhead(k+1) ...
+//   s_comm : [diag(k)]  head(k) . tail(k) . panelT(k)                                  [diag(k+1)] head(k+1) ...
+//   s_panel:             herk D(k+1) -= head head^H . POTRF(k+1)
 template <class T>
 void DeviceMatrix<T>::factorize_async() {
   Transport* tr = grid->transport.get();
@@ -458,6 +470,11 @@ void DeviceMatrix<T>::factorize_async() {
   const CommAxis ax_row = transposed ? CommAxis::Col : CommAxis::Row;
   const CommAxis ax_col = transposed ? CommAxis::Row : CommAxis::Col;
   hipStream_t s_main = s_low, s_panel = s_high;
+  const bool early = [&] {
+    if (const char* e = std::getenv("DLAF_MI355X_SCHEDULE"))
+      return std::strcmp(e, "early") == 0;
+    return dist;
+  }();
 
   for (auto& ps : prof) {
     ps.used = 0;
@@ -471,13 +488,13 @@ void DeviceMatrix<T>::factorize_async() {
 
   // algorithmic work of one grouped update launch (BASELINE.md roofline table):
   // gemm tile 2 m n k flop / (m k + n k + 2 m n) elements, herk tile n (n+1) k flop / (n k + n^2) elements
-  auto update_work = [&](long il0, long j0, long j1, int kb, double& flops, double& bytes) {
+  auto update_work = [&](long il0, long il1, long j0, long j1, int kb, double& flops, double& bytes) {
     flops = bytes = 0;
     const double cx = TypeInfo<T>::is_complex ? 4.0 : 1.0;
     for (long jl = j0; jl < j1; ++jl) {
       const long gj = cols.global_of(jl);
       const double nj = rows.tile_extent(gj);
-      for (long il = std::max(il0, rows.next_local(gj)); il < ltr; ++il) {
+      for (long il = std::max(il0, rows.next_local(gj)); il < il1; ++il) {
         const long gi = rows.global_of(il);
         const double mi = rows.tile_extent(gi);
         if (gi == gj) {
@@ -498,17 +515,21 @@ void DeviceMatrix<T>::factorize_async() {
     const T* b_base = nullptr;  // transposed panel: tile of local col jl at b_base + (jl - jl_n)*b_ts
     long b_ts = 0, il_n = 0, jl_n = 0;
     int kb = 0;
-    long rest0 = 0, split = 0;  // rest_A = [rest0, split), rest_B = [split, ltc)
+    long rest0 = 0, split = 0;  // classic: rest_A = [rest0, split), rest_B = [split, ltc); early: rest = [rest0, ltc)
     bool valid = false;
   };
 
-  // reserve: workgroup slots the launch must leave free (resident POTRF / RCCL kernels run beside it)
-  auto update = [&](const Step& st, long j0, long j1, hipStream_t s, int role, long reserve) {
+  // Update of local tile columns [j0, j1), local tile rows [max(il_from, diagonal), il_to) with the
+  // panels of step `st`.  reserve: workgroup slots the launch must leave free (resident POTRF / RCCL
+  // kernels run beside it).  kind: profile class.
+  auto update = [&](const Step& st, long j0, long j1, hipStream_t s, int role, long reserve, long il_from = -1,
+                    long il_to = -1, int kind = -1) {
     if (!st.valid || j0 >= j1)
       return;
     // rows that can hold tiles on/below the diagonal of column block j0
-    const long il0 = std::max(st.il_n, rows.next_local(cols.global_of(j0)));
-    if (il0 >= ltr)
+    const long il0 = std::max(std::max(st.il_n, il_from), rows.next_local(cols.global_of(j0)));
+    const long il1 = il_to < 0 ? ltr : std::min(il_to, ltr);
+    if (il0 >= il1)
       return;
     UpdateArgs<T> ua;
     ua.c = tiles;
@@ -522,7 +543,7 @@ void DeviceMatrix<T>::factorize_async() {
     ua.b_ts = st.b_ts;
     ua.ldb = nb;
     ua.il0 = (int) il0;
-    ua.il1 = (int) ltr;
+    ua.il1 = (int) il1;
     ua.jl0 = (int) j0;
     ua.jl1 = (int) j1;
     ua.nb = nb;
@@ -535,23 +556,112 @@ void DeviceMatrix<T>::factorize_async() {
     ua.last_rows = last_rows;
     ua.info = info;
     double fl, by;
-    update_work(il0, j0, j1, st.kb, fl, by);
-    prof_begin(role, s);
+    update_work(il0, il1, j0, j1, st.kb, fl, by);
+    const int pk = kind < 0 ? role : kind;
+    prof_begin(pk, s);
     launch_update(ua, s, role, reserve > 0 ? std::max<long>(8, bulk_slots - reserve) : 0,
                   coop_sync + 2 * (nb / kDiagBlock + 2));
-    prof_end(role, s, fl, by);
+    prof_end(pk, s, fl, by);
   };
 
-  // rest_A must last about as long as the POTRF chain of the next diagonal tile
-  // (~ (nb/64) dependent sub-steps of ~90 us) at the bulk update's rate
-  const double lookahead_flops = [&] {
-    if (const char* e = std::getenv("DLAF_MI355X_LOOKAHEAD_FLOPS"))
-      return std::atof(e);
-    return 90e-6 * ((double) nb / kDiagBlock) * 55e12;
-  }();
+  // panel TRSM of local tile rows [il0, il1) of local tile column klc with the factored diagonal tile
+  auto trsm = [&](long il0, long il1, long klc, const T* Lkk, const T* Wkk, int kb) {
+    if (il0 >= il1)
+      return;
+    TrsmArgs<T> ta;
+    ta.b = tile(il0, klc);
+    ta.b_ts = (long) tile_elems;
+    ta.ldb = nb;
+    ta.il0 = (int) il0;
+    ta.il1 = (int) il1;
+    ta.pr = rows.P;
+    ta.ri = rows.shift();
+    ta.nb = nb;
+    ta.nt = (int) nt;
+    ta.last_rows = last_rows;
+    ta.l = Lkk;
+    ta.ldl = nb;
+    ta.winv = Wkk;
+    ta.n = kb;
+    ta.info = info;
+    // algorithmic work: n^2 m flop and (n^2/2 + 2 m n) elements per tile
+    double fl = 0, by = 0;
+    for (long il = il0; il < il1; ++il) {
+      const double mi = rows.tile_extent(rows.global_of(il));
+      fl += (TypeInfo<T>::is_complex ? 4.0 : 1.0) * (double) kb * kb * mi;
+      by += (0.5 * kb * kb + 2.0 * mi * kb) * sizeof(T);
+    }
+    prof_begin(2, s_main);
+    launch_trsm(ta, s_main);
+    prof_end(2, s_main, fl, by);
+  };
 
-  // Workgroup slots kept free by the bulk launches: rest_A runs beside the cooperative POTRF of the
-  // next diagonal tile (one workgroup per 64 rows), rest_B beside the RCCL broadcasts of the step.
+  // diagonal tile k on its owner (s_panel); the inverted diagonal blocks alternate between two buffers
+  // because POTRF(k+1) may run while TRSM(k) still reads those of step k
+  auto winv_of = [&](long k) { return winv + (size_t) (k & 1) * winv_elems(); };
+  auto diag_ws_of = [&](long k) { return diag_ws + (size_t) (k & 1) * (tile_elems + winv_elems()); };
+  auto potrf = [&](long k) {
+    if (rows.rank != rows.owner(k) || cols.rank != cols.owner(k))
+      return;
+    const int kb = rows.tile_extent(k);
+    const double cxf = TypeInfo<T>::is_complex ? 4.0 : 1.0;
+    prof_begin(3, s_panel);
+    potrf_tile(tile(rows.local_of(k), cols.local_of(k)), nb, kb, winv_of(k), info, (int) (k * nb), coop_sync, s_panel);
+    prof_end(3, s_panel, cxf * (double) kb * kb * kb / 3.0, (double) kb * kb * sizeof(T));
+  };
+
+  // after POTRF(k) on s_panel: the factored tile and its inverse blocks travel down the owning process
+  // column; returns through Lkk / Wkk what TRSM(k) reads and records ev_diag[k] when that is ready
+  auto diag_bcast = [&](long k, bool in_row, bool in_col, const T*& Lkk, const T*& Wkk) {
+    Lkk = Wkk = nullptr;
+    if (in_row && in_col) {
+      Lkk = tile(rows.local_of(k), cols.local_of(k));
+      Wkk = winv_of(k);
+    }
+    if (in_col && rows.P > 1) {
+      T* ws = diag_ws_of(k);
+      if (in_row) {
+        DLAF_HIP_CHECK(hipMemcpyAsync(ws, Lkk, tile_bytes, hipMemcpyDeviceToDevice, s_panel));
+        DLAF_HIP_CHECK(hipMemcpyAsync(ws + tile_elems, Wkk, winv_elems() * sizeof(T), hipMemcpyDeviceToDevice, s_panel));
+      }
+      DLAF_HIP_CHECK(hipEventRecord(ev_diag[k], s_panel));
+      DLAF_HIP_CHECK(hipStreamWaitEvent(s_comm, ev_diag[k], 0));
+      tr->bcast(ax_col, rows.owner(k), rows.rank, ws, ws, tile_bytes + winv_elems() * sizeof(T), s_comm);
+      DLAF_HIP_CHECK(hipEventRecord(ev_diag[k], s_comm));
+      Lkk = ws;
+      Wkk = ws + tile_elems;
+    }
+    else {
+      DLAF_HIP_CHECK(hipEventRecord(ev_diag[k], s_panel));
+    }
+  };
+
+  // transposed panel of step k down the process columns (after the row broadcast), or the view of the
+  // column panel that plays its role when this process holds every row
+  auto transposed_panel = [&](long k, Step& cur, int buf) {
+    if (rows.P > 1) {
+      tr->group_begin();
+      for (long jl = cur.jl_n; jl < ltc; ++jl) {
+        const long gj = cols.global_of(jl);
+        if (gj == nt - 1)
+          continue;  // last tile row is only ever a herk operand (broadcast_panel.h:186-191)
+        const int root_r = rows.owner(gj);
+        const T* src = (rows.rank == root_r) ? cur.a_base + (size_t) (rows.local_of(gj) - cur.il_n) * tile_elems : nullptr;
+        tr->bcast(ax_col, root_r, rows.rank, src, panelT[buf] + (size_t) (jl - cur.jl_n) * tile_elems, tile_bytes, s_comm);
+      }
+      tr->group_end();
+      cur.b_base = panelT[buf];
+    }
+    else {
+      // I hold every row of the panel: tile gj sits at local row gj
+      cur.b_base = cur.a_base + (cols.global_of(cur.jl_n) - cur.il_n) * (long) tile_elems;
+      cur.b_ts = (long) tile_elems * cols.P;
+    }
+    (void) k;
+  };
+
+  // Workgroup slots kept free by the bulk launches for the cooperative POTRF of the next diagonal tile
+  // (one workgroup per 64 rows) and for the RCCL broadcast kernels of the step.
   const long potrf_slots = [&]() -> long {
     if (const char* e = std::getenv("DLAF_MI355X_POTRF_SLOTS"))
       return std::atol(e);
@@ -563,154 +673,176 @@ void DeviceMatrix<T>::factorize_async() {
     return (dist && tr->device_side()) ? 32 : 0;
   }();
 
-  Step prev;  // step k-1, whose rest_B is still to be issued
-  for (long k = 0; k < nt; ++k) {
-    const int kb = rows.tile_extent(k);
-    const int own_r = rows.owner(k), own_c = cols.owner(k);
-    const bool in_row = rows.rank == own_r, in_col = cols.rank == own_c;
-    const long il_n = rows.next_local(k + 1), jl_n = cols.next_local(k + 1);
-    const int buf = (int) (k & 1);
-    const long klc = in_col ? cols.local_of(k) : -1;
+  Step prev;  // step k-1, whose bulk update is still to be issued (in part or in full)
 
-    // ---- s_panel: diagonal tile (column k is final once U(k-1, col k) has run: ev_high[k-1]) ---------
-    const T* Lkk = nullptr;
-    const T* Wkk = nullptr;
-    if (k >= 1)
-      DLAF_HIP_CHECK(hipStreamWaitEvent(s_panel, ev_high[k - 1], 0));
-    if (in_row && in_col) {
-      T* tkk = tile(rows.local_of(k), klc);
-      const double cxf = TypeInfo<T>::is_complex ? 4.0 : 1.0;
-      prof_begin(3, s_panel);
-      potrf_tile(tkk, nb, kb, winv, info, (int) (k * nb), coop_sync, s_panel);
-      prof_end(3, s_panel, cxf * (double) kb * kb * kb / 3.0, (double) kb * kb * sizeof(T));
-      Lkk = tkk;
-      Wkk = winv;
-    }
-    if (k == nt - 1) {
-      // nothing trails the last diagonal tile; flush what is left of step k-1
-      update(prev, prev.rest0, prev.split, s_main, 0, potrf_slots);
-      update(prev, prev.split, ltc, s_main, 0, comm_slots);
-      prev.valid = false;
-      DLAF_HIP_CHECK(hipEventRecord(ev_diag[k], s_panel));
+  if (early) {
+    potrf(0);
+    for (long k = 0; k < nt; ++k) {
+      const int kb = rows.tile_extent(k);
+      const int own_c = cols.owner(k);
+      const bool in_row = rows.rank == rows.owner(k), in_col = cols.rank == own_c;
+      const long il_n = rows.next_local(k + 1), jl_n = cols.next_local(k + 1);
+      const int buf = (int) (k & 1);
+      const long klc = in_col ? cols.local_of(k) : -1;
+      if (k == nt - 1) {
+        update(prev, prev.rest0, ltc, s_main, 0, 0);  // (empty: nothing lies right of column nt-1)
+        DLAF_HIP_CHECK(hipEventRecord(ev_diag[k], s_panel));
+        DLAF_HIP_CHECK(hipStreamWaitEvent(s_main, ev_diag[k], 0));
+        break;
+      }
+      const T *Lkk, *Wkk;
+      diag_bcast(k, in_row, in_col, Lkk, Wkk);
+
+      // ---- s_main: the head tile A(k+1,k) first, then the rest of the panel -------------------------
+      // the head lives in process row owner(k+1), where it is the first local row below the diagonal
+      const bool head_row = rows.rank == rows.owner(k + 1);
+      const long il_t = il_n + (head_row ? 1 : 0);  // first local row of the tail
       DLAF_HIP_CHECK(hipStreamWaitEvent(s_main, ev_diag[k], 0));
-      break;
-    }
-    if (in_col && rows.P > 1) {
-      // diag tile (+ its inverted diagonal blocks) down the owning process column
-      if (in_row) {
-        DLAF_HIP_CHECK(hipMemcpyAsync(diag_ws, Lkk, tile_bytes, hipMemcpyDeviceToDevice, s_panel));
-        DLAF_HIP_CHECK(hipMemcpyAsync(diag_ws + tile_elems, Wkk, winv_elems() * sizeof(T), hipMemcpyDeviceToDevice,
-                                      s_panel));
-      }
-      DLAF_HIP_CHECK(hipEventRecord(ev_diag[k], s_panel));
-      DLAF_HIP_CHECK(hipStreamWaitEvent(s_comm, ev_diag[k], 0));
-      tr->bcast(ax_col, own_r, rows.rank, diag_ws, diag_ws, tile_bytes + winv_elems() * sizeof(T), s_comm);
-      DLAF_HIP_CHECK(hipEventRecord(ev_diag[k], s_comm));
-      Lkk = diag_ws;
-      Wkk = diag_ws + tile_elems;
-    }
-    else {
-      DLAF_HIP_CHECK(hipEventRecord(ev_diag[k], s_panel));
-    }
+      if (in_col && head_row)
+        trsm(il_n, il_n + 1, klc, Lkk, Wkk, kb);
+      DLAF_HIP_CHECK(hipEventRecord(ev_head[k], s_main));
+      if (in_col)
+        trsm(il_t, ltr, klc, Lkk, Wkk, kb);
+      DLAF_HIP_CHECK(hipEventRecord(ev_panel[k], s_main));
 
-    // ---- s_main: first slice of the previous step's bulk update runs beside the POTRF chain -----------
-    update(prev, prev.rest0, prev.split, s_main, 0, potrf_slots);
-
-    // ---- s_main: panel TRSM ------------------------------------------------------------------------------
-    DLAF_HIP_CHECK(hipStreamWaitEvent(s_main, ev_diag[k], 0));
-    if (in_col && il_n < ltr) {
-      TrsmArgs<T> ta;
-      ta.b = tile(il_n, klc);
-      ta.b_ts = (long) tile_elems;
-      ta.ldb = nb;
-      ta.il0 = (int) il_n;
-      ta.il1 = (int) ltr;
-      ta.pr = rows.P;
-      ta.ri = rows.shift();
-      ta.nb = nb;
-      ta.nt = (int) nt;
-      ta.last_rows = last_rows;
-      ta.l = Lkk;
-      ta.ldl = nb;
-      ta.winv = Wkk;
-      ta.n = kb;
-      ta.info = info;
-      // algorithmic work: n^2 m flop and (n^2/2 + 2 m n) elements per tile
-      double fl = 0, by = 0;
-      for (long il = il_n; il < ltr; ++il) {
-        const double mi = rows.tile_extent(rows.global_of(il));
-        fl += (TypeInfo<T>::is_complex ? 4.0 : 1.0) * (double) kb * kb * mi;
-        by += (0.5 * kb * kb + 2.0 * mi * kb) * sizeof(T);
-      }
-      prof_begin(2, s_main);
-      launch_trsm(ta, s_main);
-      prof_end(2, s_main, fl, by);
-    }
-    DLAF_HIP_CHECK(hipEventRecord(ev_panel[k], s_main));
-
-    // ---- s_comm: panel along process rows, transposed panel along process columns --------------------
-    Step cur;
-    cur.valid = true;
-    cur.kb = kb;
-    cur.il_n = il_n;
-    cur.jl_n = jl_n;
-    cur.b_ts = (long) tile_elems;
-    if (dist)
-      DLAF_HIP_CHECK(hipStreamWaitEvent(s_comm, ev_panel[k], 0));
-    if (cols.P > 1) {
-      // the workspace of step k-2 is free: its readers are behind TRSM(k) on s_main (ev_panel[k])
+      // ---- s_comm: head, tail along process rows; transposed panel along process columns -----------
+      Step cur;
+      cur.valid = true;
+      cur.kb = kb;
+      cur.il_n = il_n;
+      cur.jl_n = jl_n;
+      cur.b_ts = (long) tile_elems;
+      // the workspace of step k-2 is free: its readers are behind TRSM(k) on s_main (ev_head[k])
       T* dst = in_col ? tile(il_n < ltr ? il_n : 0, klc) : panel[buf];
-      if (il_n < ltr)
-        tr->bcast(ax_row, own_c, cols.rank, dst, dst, (size_t) (ltr - il_n) * tile_bytes, s_comm);
       cur.a_base = dst;
-    }
-    else {
-      cur.a_base = tile(il_n < ltr ? il_n : 0, klc);
-    }
-    if (rows.P > 1) {
-      tr->group_begin();
-      for (long jl = jl_n; jl < ltc; ++jl) {
-        const long gj = cols.global_of(jl);
-        if (gj == nt - 1)
-          continue;  // last tile row is only ever a herk operand (broadcast_panel.h:186-191)
-        const int root_r = rows.owner(gj);
-        const T* src = (rows.rank == root_r) ? cur.a_base + (size_t) (rows.local_of(gj) - il_n) * tile_elems : nullptr;
-        tr->bcast(ax_col, root_r, rows.rank, src, panelT[buf] + (size_t) (jl - jl_n) * tile_elems, tile_bytes, s_comm);
-      }
-      tr->group_end();
-      cur.b_base = panelT[buf];
-    }
-    else {
-      // I hold every row of the panel: tile gj sits at local row gj
-      cur.b_base = cur.a_base + (cols.global_of(jl_n) - il_n) * (long) tile_elems;
-      cur.b_ts = (long) tile_elems * cols.P;
-    }
-    if (dist)
-      DLAF_HIP_CHECK(hipEventRecord(ev_bcast[k], s_comm));
+      if (dist)
+        DLAF_HIP_CHECK(hipStreamWaitEvent(s_comm, ev_head[k], 0));
+      if (cols.P > 1 && head_row)
+        tr->bcast(ax_row, own_c, cols.rank, dst, dst, tile_bytes, s_comm);
+      if (dist)
+        DLAF_HIP_CHECK(hipEventRecord(ev_headb[k], s_comm));
 
-    // ---- s_main: rest of step k-1 (the broadcasts of step k fly underneath) ---------------------------
-    update(prev, prev.split, ltc, s_main, 0, comm_slots);
-    if (dist)
-      DLAF_HIP_CHECK(hipStreamWaitEvent(s_main, ev_bcast[k], 0));
-
-    // ---- s_main: lookahead column of step k, then split the rest ------------------------------------
-    cur.rest0 = jl_n;
-    if (cols.mine(k + 1) && jl_n < ltc) {
-      update(cur, jl_n, jl_n + 1, s_main, 1, 0);
-      cur.rest0 = jl_n + 1;
-    }
-    DLAF_HIP_CHECK(hipEventRecord(ev_high[k], s_main));
-    cur.split = cur.rest0;
-    {
-      double acc = 0;
-      while (cur.split < ltc && acc < lookahead_flops) {
-        double fl, by;
-        update_work(std::max(il_n, rows.next_local(cols.global_of(cur.split))), cur.split, cur.split + 1, kb, fl, by);
-        acc += fl;
-        ++cur.split;
+      // ---- s_panel: D(k+1) -= head head^H, POTRF(k+1) -------------------------------------------------
+      // (every earlier update of D(k+1) is in the two-column lookahead of step k-1: ev_high[k-1])
+      if (head_row && cols.rank == cols.owner(k + 1)) {
+        if (k >= 1)
+          DLAF_HIP_CHECK(hipStreamWaitEvent(s_panel, ev_high[k - 1], 0));
+        DLAF_HIP_CHECK(hipStreamWaitEvent(s_panel, (dist && cols.P > 1) ? ev_headb[k] : ev_head[k], 0));
+        Step head = cur;
+        head.b_base = cur.a_base;  // the herk tile takes both operands from the column panel
+        update(head, jl_n, jl_n + 1, s_panel, 2, 0, il_n, il_n + 1, 3);
+        potrf(k + 1);
       }
+
+      if (dist)
+        DLAF_HIP_CHECK(hipStreamWaitEvent(s_comm, ev_panel[k], 0));
+      if (cols.P > 1 && il_t < ltr)
+        tr->bcast(ax_row, own_c, cols.rank, dst + (size_t) (il_t - il_n) * tile_elems,
+                  dst + (size_t) (il_t - il_n) * tile_elems, (size_t) (ltr - il_t) * tile_bytes, s_comm);
+      transposed_panel(k, cur, buf);
+      if (dist)
+        DLAF_HIP_CHECK(hipEventRecord(ev_bcast[k], s_comm));
+
+      // ---- s_main: bulk of step k-1 beside the broadcasts of step k and POTRF(k+1) -----------------
+      update(prev, prev.rest0, ltc, s_main, 0, potrf_slots + comm_slots);
+      if (dist)
+        DLAF_HIP_CHECK(hipStreamWaitEvent(s_main, ev_bcast[k], 0));
+
+      // ---- s_main: two-column lookahead of step k (D(k+1) itself is on s_panel) ----------------------
+      cur.rest0 = cols.next_local(k + 3);
+      update(cur, jl_n, cur.rest0, s_main, 1, 0, rows.next_local(k + 2));
+      DLAF_HIP_CHECK(hipEventRecord(ev_high[k], s_main));
+      prev = cur;
     }
-    prev = cur;
+  }
+  else {
+    // rest_A must last about as long as the POTRF chain of the next diagonal tile
+    // (~ (nb/64) dependent sub-steps of ~90 us) at the bulk update's rate
+    const double lookahead_flops = [&] {
+      if (const char* e = std::getenv("DLAF_MI355X_LOOKAHEAD_FLOPS"))
+        return std::atof(e);
+      return 90e-6 * ((double) nb / kDiagBlock) * 55e12;
+    }();
+    for (long k = 0; k < nt; ++k) {
+      const int kb = rows.tile_extent(k);
+      const int own_c = cols.owner(k);
+      const bool in_row = rows.rank == rows.owner(k), in_col = cols.rank == own_c;
+      const long il_n = rows.next_local(k + 1), jl_n = cols.next_local(k + 1);
+      const int buf = (int) (k & 1);
+      const long klc = in_col ? cols.local_of(k) : -1;
+
+      // ---- s_panel: diagonal tile (column k is final once U(k-1, col k) has run: ev_high[k-1]) -------
+      if (k >= 1)
+        DLAF_HIP_CHECK(hipStreamWaitEvent(s_panel, ev_high[k - 1], 0));
+      potrf(k);
+      if (k == nt - 1) {
+        // nothing trails the last diagonal tile; flush what is left of step k-1
+        update(prev, prev.rest0, prev.split, s_main, 0, potrf_slots);
+        update(prev, prev.split, ltc, s_main, 0, comm_slots);
+        prev.valid = false;
+        DLAF_HIP_CHECK(hipEventRecord(ev_diag[k], s_panel));
+        DLAF_HIP_CHECK(hipStreamWaitEvent(s_main, ev_diag[k], 0));
+        break;
+      }
+      const T *Lkk, *Wkk;
+      diag_bcast(k, in_row, in_col, Lkk, Wkk);
+
+      // ---- s_main: first slice of the previous step's bulk update runs beside the POTRF -------------
+      update(prev, prev.rest0, prev.split, s_main, 0, potrf_slots);
+
+      // ---- s_main: panel TRSM --------------------------------------------------------------------------
+      DLAF_HIP_CHECK(hipStreamWaitEvent(s_main, ev_diag[k], 0));
+      if (in_col)
+        trsm(il_n, ltr, klc, Lkk, Wkk, kb);
+      DLAF_HIP_CHECK(hipEventRecord(ev_panel[k], s_main));
+
+      // ---- s_comm: panel along process rows, transposed panel along process columns ----------------
+      Step cur;
+      cur.valid = true;
+      cur.kb = kb;
+      cur.il_n = il_n;
+      cur.jl_n = jl_n;
+      cur.b_ts = (long) tile_elems;
+      if (dist)
+        DLAF_HIP_CHECK(hipStreamWaitEvent(s_comm, ev_panel[k], 0));
+      if (cols.P > 1) {
+        // the workspace of step k-2 is free: its readers are behind TRSM(k) on s_main (ev_panel[k])
+        T* dst = in_col ? tile(il_n < ltr ? il_n : 0, klc) : panel[buf];
+        if (il_n < ltr)
+          tr->bcast(ax_row, own_c, cols.rank, dst, dst, (size_t) (ltr - il_n) * tile_bytes, s_comm);
+        cur.a_base = dst;
+      }
+      else {
+        cur.a_base = tile(il_n < ltr ? il_n : 0, klc);
+      }
+      transposed_panel(k, cur, buf);
+      if (dist)
+        DLAF_HIP_CHECK(hipEventRecord(ev_bcast[k], s_comm));
+
+      // ---- s_main: rest of step k-1 (the broadcasts of step k fly underneath) -------------------------
+      update(prev, prev.split, ltc, s_main, 0, comm_slots);
+      if (dist)
+        DLAF_HIP_CHECK(hipStreamWaitEvent(s_main, ev_bcast[k], 0));
+
+      // ---- s_main: lookahead column of step k, then split the rest ----------------------------------
+      cur.rest0 = jl_n;
+      if (cols.mine(k + 1) && jl_n < ltc) {
+        update(cur, jl_n, jl_n + 1, s_main, 1, 0);
+        cur.rest0 = jl_n + 1;
+      }
+      DLAF_HIP_CHECK(hipEventRecord(ev_high[k], s_main));
+      cur.split = cur.rest0;
+      {
+        double acc = 0;
+        while (cur.split < ltc && acc < lookahead_flops) {
+          double fl, by;
+          update_work(std::max(il_n, rows.next_local(cols.global_of(cur.split))), ltr, cur.split, cur.split + 1, kb, fl, by);
+          acc += fl;
+          ++cur.split;
+        }
+      }
+      prev = cur;
+    }
   }
   DLAF_HIP_CHECK(hipEventRecord(ev_low[0], s_main));
   DLAF_HIP_CHECK(hipStreamWaitEvent(s_panel, ev_low[0], 0));

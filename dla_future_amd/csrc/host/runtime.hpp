@@ -92,8 +92,8 @@ struct DeviceMatrix : MatrixBase {
   size_t tile_elems = 0;    // nb*nb
 
   T* tiles = nullptr;       // ltr*ltc tiles
-  T* diag_ws = nullptr;     // nb*nb + ceil(nb/64)*64*64: received diagonal tile + its inverse blocks
-  T* winv = nullptr;        // ceil(nb/64) * 64*64 inverted diagonal blocks (owner side)
+  T* diag_ws = nullptr;     // 2 x (nb*nb + ceil(nb/64)*64*64): received diagonal tile + its inverse blocks
+  T* winv = nullptr;        // 2 x ceil(nb/64) * 64*64 inverted diagonal blocks (owner side)
   T* panel[2] = {nullptr, nullptr};   // ltr tiles each (received column panel)
   T* panelT[2] = {nullptr, nullptr};  // ltc tiles each (transposed panel)
   T* staging = nullptr;     // column-major staging for upload/download
@@ -103,7 +103,7 @@ struct DeviceMatrix : MatrixBase {
   int* info_host = nullptr; // pinned
 
   hipStream_t s_high = nullptr, s_low = nullptr, s_comm = nullptr;
-  std::vector<hipEvent_t> ev_panel, ev_low, ev_high, ev_diag, ev_bcast, ev_bcastT;
+  std::vector<hipEvent_t> ev_panel, ev_low, ev_high, ev_diag, ev_bcast, ev_bcastT, ev_head, ev_headb;
 
   // live timing of the launch classes with HIP events on the stream each class runs on
   // (kind 0: trailing bulk update, 1: lookahead-column update, 2: panel TRSM, 3: tile POTRF chain)

@@ -24,7 +24,7 @@ def free_port():
     return p
 
 
-def launch(mode, nprow, npcol, order, timeout):
+def launch(mode, nprow, npcol, order, timeout, extra_env=None):
     """Start one worker process per rank directly (no launcher process: the GPU box allows at most 6
     processes on the card, and 3x2 / 2x3 grids need all of them)."""
     n = nprow * npcol
@@ -33,6 +33,7 @@ def launch(mode, nprow, npcol, order, timeout):
     for rank in range(n):
         env = dict(os.environ, OMP_NUM_THREADS="1", DLAF_MI355X_DEVICE="0", RANK=str(rank), WORLD_SIZE=str(n),
                    LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), mode, str(nprow),
                                        str(npcol), order], cwd=ROOT, env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
@@ -58,6 +59,13 @@ def test_grid_wiring_and_generation_gloo_cpu(nprow, npcol, order):
 @pytest.mark.parametrize("nprow,npcol,order", [(1, 2, "R"), (2, 1, "R"), (2, 2, "C"), (3, 2, "R"), (2, 3, "C")])
 def test_distributed_cholesky_one_gpu_many_ranks(nprow, npcol, order):
     launch("gpu", nprow, npcol, order, timeout=600)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nprow,npcol,order", [(2, 2, "R"), (1, 3, "R")])
+def test_distributed_cholesky_classic_schedule(nprow, npcol, order):
+    """Process grids default to the early-diagonal issue order; the classic one stays selectable."""
+    launch("gpu", nprow, npcol, order, timeout=600, extra_env={"DLAF_MI355X_SCHEDULE": "classic"})
 
 
 RCCL_SINGLE = r"""

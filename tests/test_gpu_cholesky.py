@@ -41,10 +41,18 @@ def test_cholesky_local_analytic(dlaf, grid, oracle, t, uplo):
         assert (store[m:, :] == 4.4).all()
 
 
+@pytest.fixture(params=["classic", "early"])
+def schedule(request, monkeypatch):
+    """Both issue orders of the tile DAG (runtime.cpp: classic = one-process default, early diagonal =
+    process-grid default); DLAF_MI355X_SCHEDULE is read at every factorization."""
+    monkeypatch.setenv("DLAF_MI355X_SCHEDULE", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("t", TYPES)
 @pytest.mark.parametrize("uplo", ["L", "U"])
-def test_cholesky_random_vs_oracle(dlaf, grid, oracle, t, uplo):
-    for n, nb in [(300, 64), (515, 128), (1024, 256)]:
+def test_cholesky_random_vs_oracle(dlaf, grid, oracle, t, uplo, schedule):
+    for n, nb in [(300, 64), (515, 128), (1024, 256), (64, 64), (100, 64), (129, 64), (200, 32)]:
         dt = oracle.DTYPES[t]
         a0 = oracle.set_random_hpd(n, nb, dt)
         ref = a0.copy(order="F")
