@@ -189,6 +189,17 @@ def main():
         check = diff / norm_a
 
     if rank == 0:
+        # HBM-side bytes of the dominant kernel come from PMC passes (FETCH_SIZE / WRITE_SIZE cannot be
+        # read from inside the process): profiles/pmc_traffic.json holds the figure measured for one
+        # workload, quoted here only when this run is that workload
+        traffic = traffic_src = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+                pt = json.load(fh)
+            if pt["workload"] == f"cholesky_{args.type} N={n} nb={nb} uplo={args.uplo}" and pt["grid"] == f"{nprow}x{npcol}":
+                traffic, traffic_src = pt["bytes_per_launch"], pt["source"]
+        except (OSError, KeyError, ValueError):
+            pass
         bulk = prof["update_bulk"]
         trsm = prof["trsm_panel"]
         ach = bulk["flops"] / (bulk["ms"] * 1e-3) / 1e12 if bulk["ms"] > 0 else 0.0
@@ -205,7 +216,10 @@ def main():
             "fraction_of_fp64_mfma_peak": round(tflops / (world * PEAK_FP64_MFMA_TFLOPS), 4),
             "roofline": {"kernel": "update_kernel<T,VEC,0> (grouped trailing herk+gemm)", "bound": "mfma",
                          "achieved": round(ach, 3), "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFlop/s",
-                         "frac": round(ach / PEAK_FP64_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(ach / PEAK_FP64_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, Infinity-Cache hits included)",
+                         "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": bulk["bytes"] / max(1, bulk["launches"]),
                          "launches": bulk["launches"], "avg_launch_ms": round(bulk["ms"] / max(1, bulk["launches"]), 4),
                          "algorithmic_flop_per_launch": bulk["flops"] / max(1, bulk["launches"])},
             "trsm_panel": {"bound": "hbm", "achieved_GBps": round(trsm["bytes"] / max(trsm["ms"], 1e-9) / 1e6, 1),

@@ -114,6 +114,10 @@ __device__ __forceinline__ void update_block(const UpdateArgs<T>& p, const Updat
   // transposed panel never holds the tile of the last global row (broadcast_panel.h:186-191)
   const T* B = diag ? p.a + (long) (il - p.il0) * p.a_ts + n0 : p.b + (long) (jl - p.jl0) * p.b_ts + n0;
   const long ldb = diag ? p.lda : p.ldb;
+#ifdef DLAF_DBG_SAME_STRIPS
+  A = p.a;  // tuning aid (tools/update_bench.hip): every block streams the same two strips = perfect L2 locality
+  B = p.b;
+#endif
   T* C = p.c + (long) il * p.c_tsr + (long) jl * p.c_tsc + m0 + (long) n0 * p.ldc;
 
   const bool full = (mrows == Cfg::BM) && (ncols == Cfg::BN) && (p.K % Cfg::BK == 0);

@@ -756,12 +756,13 @@ void DeviceMatrix<T>::factorize_async() {
     }
   }
   else {
-    // rest_A must last about as long as the POTRF chain of the next diagonal tile
-    // (~ (nb/64) dependent sub-steps of ~90 us) at the bulk update's rate
+    // rest_A must last as long as the POTRF of the next diagonal tile takes BESIDE it: nb/64 dependent
+    // sub-steps of ~90 us alone, 2-3x that under the bulk kernel's memory traffic (measured at nb = 1024:
+    // 1.1 ms alone, 2.2-3.4 ms beside rest_A; the whole factorization is fastest with rest_A ~ 4 ms)
     const double lookahead_flops = [&] {
       if (const char* e = std::getenv("DLAF_MI355X_LOOKAHEAD_FLOPS"))
         return std::atof(e);
-      return 90e-6 * ((double) nb / kDiagBlock) * 55e12;
+      return 270e-6 * ((double) nb / kDiagBlock) * 55e12;
     }();
     for (long k = 0; k < nt; ++k) {
       const int kb = rows.tile_extent(k);
