@@ -78,6 +78,14 @@ SIGNATURES = {
     "dlaf_mi355x_cholesky_residual": (_i, [_vp, _vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dlaf_mi355x_matrix_profile": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_long),
                                         C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "dlaf_mi355x_triangular_solver_s": (_i, [_i, _ch, _ch, _ch, _ch, _vp, _vp, DLAFDescriptor, _vp, DLAFDescriptor]),
+    "dlaf_mi355x_triangular_solver_d": (_i, [_i, _ch, _ch, _ch, _ch, _vp, _vp, DLAFDescriptor, _vp, DLAFDescriptor]),
+    "dlaf_mi355x_triangular_solver_c": (_i, [_i, _ch, _ch, _ch, _ch, _vp, _vp, DLAFDescriptor, _vp, DLAFDescriptor]),
+    "dlaf_mi355x_triangular_solver_z": (_i, [_i, _ch, _ch, _ch, _ch, _vp, _vp, DLAFDescriptor, _vp, DLAFDescriptor]),
+    "dlaf_mi355x_pstrsm": (None, [_ch, _ch, _ch, _ch, _i, _i, _vp, _vp, _i, _i, _IP, _vp, _i, _i, _IP]),
+    "dlaf_mi355x_pdtrsm": (None, [_ch, _ch, _ch, _ch, _i, _i, _vp, _vp, _i, _i, _IP, _vp, _i, _i, _IP]),
+    "dlaf_mi355x_pctrsm": (None, [_ch, _ch, _ch, _ch, _i, _i, _vp, _vp, _i, _i, _IP, _vp, _i, _i, _IP]),
+    "dlaf_mi355x_pztrsm": (None, [_ch, _ch, _ch, _ch, _i, _i, _vp, _vp, _i, _i, _IP, _vp, _i, _i, _IP]),
     "dlaf_mi355x_set_random_hpd": (_i, [_i, _ch, _vp, DLAFDescriptor, _i]),
     "dlaf_mi355x_tile_potrf": (_i, [_ch, _ch, _i, _vp, _i]),
     "dlaf_mi355x_tile_trsm": (_i, [_ch, _ch, _i, _i, _vp, _i, _vp, _i]),

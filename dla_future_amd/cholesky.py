@@ -157,6 +157,40 @@ def pxpotrf(uplo: str, n: int, a: np.ndarray, ia: int, ja: int, desca) -> int:
     return info.value
 
 
+def triangular_solver(grid: Grid, side: str, uplo: str, op: str, diag: str, alpha, a: np.ndarray, b: np.ndarray,
+                      nb: int, m: int | None = None, n: int | None = None, a_src=(0, 0), b_src=(0, 0)) -> None:
+    """dlaf::triangular_solver(grid, side, uplo, op, diag, alpha, A, B)
+    (include/dlaf/solver/triangular.h:41-177) == dlaf_mi355x_triangular_solver_{s,d,c,z}:
+    side 'L': op(A) X = alpha B, side 'R': X op(A) = alpha B; `b` (this process's local column-major part of
+    the m x n right-hand sides) is overwritten by X.  `a`: local part of the triangular matrix."""
+    t = type_char(b.dtype)
+    if a.dtype != b.dtype:
+        raise ValueError("A and B must have the same element type")
+    if m is None or n is None:
+        if grid.nranks != 1:
+            raise ValueError("the global size m x n of B is required on a distributed grid")
+        m, n = b.shape
+    na = m if side.upper() == "L" else n
+    da = DLAFDescriptor(na, na, nb, nb, a_src[0], a_src[1], 0, 0, _ld_of(a))
+    db = DLAFDescriptor(m, n, nb, nb, b_src[0], b_src[1], 0, 0, _ld_of(b))
+    al = np.array([alpha], dtype=b.dtype)
+    fn = getattr(lib(), f"dlaf_mi355x_triangular_solver_{t}")
+    r = fn(grid.context, side.encode(), uplo.encode(), op.encode(), diag.encode(), _ptr(al), _ptr(a), da, _ptr(b), db)
+    if r != 0:
+        raise ValueError(f"dlaf_mi355x_triangular_solver_{t} failed with {r}")
+
+
+def pxtrsm(side: str, uplo: str, op: str, diag: str, m: int, n: int, alpha, a: np.ndarray, ia: int, ja: int, desca,
+           b: np.ndarray, ib: int, jb: int, descb) -> None:
+    """dlaf_mi355x_p{s,d,c,z}trsm: ScaLAPACK's p?trsm argument list (9-int descriptors)."""
+    t = type_char(b.dtype)
+    da = (C.c_int * 9)(*[int(x) for x in desca])
+    db = (C.c_int * 9)(*[int(x) for x in descb])
+    al = np.array([alpha], dtype=b.dtype)
+    getattr(lib(), f"dlaf_mi355x_p{t}trsm")(side.encode(), uplo.encode(), op.encode(), diag.encode(), m, n, _ptr(al),
+                                            _ptr(a), ia, ja, da, _ptr(b), ib, jb, db)
+
+
 def set_random_hermitian_positive_definite(grid: Grid, a: np.ndarray, n: int, nb: int, isrc: int = 0,
                                            jsrc: int = 0, nthreads: int = 0) -> None:
     """matrix::util::set_random_hermitian_positive_definite (include/dlaf/util_matrix.h:498-501) on

@@ -39,6 +39,10 @@ struct UpdateArgs {
   int pr, ri, pc, ci;
   int nt, last_rows;
   const int* info;  // device flag: non-zero => a previous POTRF failed, kernels return at once
+  // rect != 0: every tile of the rectangle is a gemm (no triangle, no herk); the column axis then has its
+  // own tile count / last extent (the triangular solver updates an m x n right-hand side, solver.cpp)
+  int rect = 0;
+  int nt_c = 0, last_cols = 0;
 };
 // role: 0 trailing bulk, 1 lookahead column, 2 in-tile POTRF update (same code, separate kernel names)
 // max_blocks > 0 (with counters = 8 device words of scratch): launch at most that many workgroups and
@@ -68,6 +72,9 @@ struct TrsmArgs {
   const T* winv;
   int n;
   const int* info;
+  // upper != 0: X(il) = B(il) * U^-H with U = l upper triangular (the 64-column blocks are swept right to
+  // left); winv block j then holds inv(U_jj) (upper triangle valid, rest zero)
+  int upper = 0;
 };
 template <class T>
 void launch_trsm(const TrsmArgs<T>& args, hipStream_t stream);
@@ -77,10 +84,17 @@ void launch_trsm(const TrsmArgs<T>& args, hipStream_t stream);
 // overwritten by its lower Cholesky factor (strict upper part untouched); winv_block (64 x 64,
 // ld 64) receives inv(L) (lower, zero elsewhere).  On a non-positive pivot at column c the
 // kernel stores info_base + c + 1 into *info (first failure wins) and leaves garbage.
-// factor == false: a already holds a lower triangular matrix; only winv_block is produced.
+// factor == false: a already holds a triangular matrix; only winv_block is produced.  In that mode
+// upper: a is upper triangular and winv_block receives inv(a) (upper); unit: the diagonal of a is taken as 1.
 template <class T>
 void launch_potrf_diag(T* a, int lda, int jb, T* winv_block, int* info, int info_base, hipStream_t stream,
-                       bool factor = true);
+                       bool factor = true, bool upper = false, bool unit = false);
+
+// All ceil(kb/64) diagonal 64 x 64 blocks of one triangular kb x kb tile inverted in ONE launch (the
+// triangular solver's per-tile preparation; nothing is factored, the tile is only read).
+template <class T>
+void launch_invert_diag_blocks(const T* tile, int ld, int kb, T* winv, int* info, hipStream_t stream, bool upper,
+                               bool unit);
 
 // Whole diagonal tile (kb x kb, ld) in one resident cooperative launch of ceil(kb/64) workgroups:
 // lower Cholesky factor in place + the ceil(kb/64) inverted diagonal blocks in winv.  sync: device
@@ -108,6 +122,11 @@ struct LayoutArgs {
   long rows, cols;  // local element extents of the VIEW
   int pr, ri, pc, ci;  // global tile index of view-tile: gi = il*pr + ri, gj = jl*pc + ci
   int transpose;
+  // general matrices (triangular solver operands): full != 0 moves every tile of the rectangle (no uplo
+  // triangle); conj != 0 conjugates on the way (with transpose: the conjugate-transposed view); to-tiles
+  // only: scale != 0 multiplies by alpha (the solver's alpha * B)
+  int full = 0, conj = 0, scale = 0;
+  T alpha{};
 };
 template <class T>
 void launch_to_tiles(const LayoutArgs<T>& args, hipStream_t stream);

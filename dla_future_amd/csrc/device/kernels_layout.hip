@@ -21,9 +21,23 @@ __global__ __launch_bounds__(kThreads) void layout_kernel(LayoutArgs<T> p, int s
   __shared__ T buf[kLT][kLT + 1];
   const int il = blockIdx.y, jl = blockIdx.z;
   const int gi = il * p.pr + p.ri, gj = jl * p.pc + p.ci;
-  if (gi < gj)
+  if (!p.full && gi < gj)
     return;
-  const bool diag = (gi == gj);
+  const bool diag = !p.full && (gi == gj);
+  // element transform on the way: conjugation, and alpha * x into the tiles
+  auto xf = [&](T v) -> T {
+    if constexpr (TypeInfo<T>::is_complex) {
+      if (p.conj)
+        v.im = -v.im;
+      if (TO_TILES && p.scale)
+        v = T{v.re * p.alpha.re - v.im * p.alpha.im, v.re * p.alpha.im + v.im * p.alpha.re};
+    }
+    else {
+      if (TO_TILES && p.scale)
+        v = v * p.alpha;
+    }
+    return v;
+  };
   const int r0 = (blockIdx.x % sb) * kLT, c0 = (blockIdx.x / sb) * kLT;
   const long vrow0 = (long) il * p.nb, vcol0 = (long) jl * p.nb;  // view element origin of the tile
   const int rows_tile = (int) min((long) p.nb, p.rows - vrow0);
@@ -42,9 +56,9 @@ __global__ __launch_bounds__(kThreads) void layout_kernel(LayoutArgs<T> p, int s
         T* td = tile + r + (long) c * p.nb;
         T* cd = p.cm + (vrow0 + r) + (vcol0 + c) * p.ld_cm;
         if (TO_TILES)
-          *td = *cd;
+          *td = xf(*cd);
         else if (!diag || r >= c)
-          *cd = *td;
+          *cd = xf(*td);
       }
     }
   }
@@ -54,7 +68,7 @@ __global__ __launch_bounds__(kThreads) void layout_kernel(LayoutArgs<T> p, int s
       for (int rr = ty; rr < kLT; rr += kThreads / kLT) {
         const int r = r0 + rr, c = c0 + tx;
         if (r < rows_tile && c < cols_tile)
-          buf[rr][tx] = p.cm[(vcol0 + c) + (vrow0 + r) * p.ld_cm];
+          buf[rr][tx] = xf(p.cm[(vcol0 + c) + (vrow0 + r) * p.ld_cm]);
       }
       __syncthreads();
       for (int cc = ty; cc < kLT; cc += kThreads / kLT) {
@@ -67,7 +81,7 @@ __global__ __launch_bounds__(kThreads) void layout_kernel(LayoutArgs<T> p, int s
       for (int cc = ty; cc < kLT; cc += kThreads / kLT) {
         const int r = r0 + tx, c = c0 + cc;
         if (r < rows_tile && c < cols_tile)
-          buf[tx][cc] = tile[r + (long) c * p.nb];
+          buf[tx][cc] = xf(tile[r + (long) c * p.nb]);
       }
       __syncthreads();
       for (int rr = ty; rr < kLT; rr += kThreads / kLT) {

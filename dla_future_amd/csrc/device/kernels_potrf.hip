@@ -21,7 +21,7 @@ namespace dlaf_mi355x {
 template <class T>
 __global__ __launch_bounds__(kThreads) void potrf_diag_kernel(T* __restrict__ a, int lda, int jb,
                                                                T* __restrict__ winv, int* info, int info_base,
-                                                               int factor) {
+                                                               int factor, int upper, int unit, int n_total) {
   using R = real_t<T>;
   constexpr bool CX = TypeInfo<T>::is_complex;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -34,6 +34,12 @@ __global__ __launch_bounds__(kThreads) void potrf_diag_kernel(T* __restrict__ a,
 
   if (*info != 0)
     return;
+  if (n_total > 0) {
+    // batched invert-only form: workgroup b handles the b-th 64 x 64 diagonal block of an n_total x n_total tile
+    a += (long) blockIdx.x * kPD * (lda + 1);
+    winv += (long) blockIdx.x * kPD * kPD;
+    jb = min(kPD, n_total - (int) blockIdx.x * kPD);
+  }
   if (t == 0)
     fail_col = -1;
 
@@ -42,9 +48,14 @@ __global__ __launch_bounds__(kThreads) void potrf_diag_kernel(T* __restrict__ a,
     const int r = idx % kPD, c = idx / kPD;
     R re = 0, im = 0;
     if (r < jb && c < jb && r >= c) {
-      const T v = a[r + (long) c * lda];
+      // upper (invert-only mode): work on L' = U^H, inv(U) = inv(L')^H is written back transposed below
+      const T v = upper ? a[c + (long) r * lda] : a[r + (long) c * lda];
       re = re_of(v);
-      im = im_of(v);
+      im = upper ? -im_of(v) : im_of(v);
+      if (unit && r == c) {
+        re = 1;
+        im = 0;
+      }
     }
     if (r == c && r >= jb)
       re = 1;
@@ -78,9 +89,16 @@ __global__ __launch_bounds__(kThreads) void potrf_diag_kernel(T* __restrict__ a,
     }
     R wre = 0, wim = 0;
     if (rr < jb && cc < jb) {
-      wre = Wre[cc * kPDLd + rr];
-      if constexpr (CX)
-        wim = Wim[cc * kPDLd + rr];
+      if (upper) {
+        wre = Wre[rr * kPDLd + cc];
+        if constexpr (CX)
+          wim = -Wim[rr * kPDLd + cc];
+      }
+      else {
+        wre = Wre[cc * kPDLd + rr];
+        if constexpr (CX)
+          wim = Wim[cc * kPDLd + rr];
+      }
     }
     winv[rr + (long) cc * kPD] = make_el<T>(wre, wim);
   }
@@ -93,11 +111,21 @@ static constexpr int potrf_lds_bytes() {
 
 template <class T>
 void launch_potrf_diag(T* a, int lda, int jb, T* winv_block, int* info, int info_base, hipStream_t stream,
-                       bool factor) {
+                       bool factor, bool upper, bool unit) {
   if (jb <= 0)
     return;
   hipLaunchKernelGGL((potrf_diag_kernel<T>), dim3(1), dim3(kThreads), potrf_lds_bytes<T>(), stream, a, lda, jb,
-                     winv_block, info, info_base, factor ? 1 : 0);
+                     winv_block, info, info_base, factor ? 1 : 0, (!factor && upper) ? 1 : 0, (!factor && unit) ? 1 : 0, 0);
+}
+
+template <class T>
+void launch_invert_diag_blocks(const T* tile, int ld, int kb, T* winv, int* info, hipStream_t stream, bool upper,
+                               bool unit) {
+  if (kb <= 0)
+    return;
+  hipLaunchKernelGGL((potrf_diag_kernel<T>), dim3((unsigned) ((kb + kPD - 1) / kPD)), dim3(kThreads),
+                     potrf_lds_bytes<T>(), stream, const_cast<T*>(tile), ld, kPD, winv, info, 0, 0, upper ? 1 : 0,
+                     unit ? 1 : 0, kb);
 }
 
 template <class T>
@@ -113,9 +141,13 @@ void potrf_kernels_init() {
   potrf_init_one<cdouble>();
 }
 
-template void launch_potrf_diag<float>(float*, int, int, float*, int*, int, hipStream_t, bool);
-template void launch_potrf_diag<double>(double*, int, int, double*, int*, int, hipStream_t, bool);
-template void launch_potrf_diag<cfloat>(cfloat*, int, int, cfloat*, int*, int, hipStream_t, bool);
-template void launch_potrf_diag<cdouble>(cdouble*, int, int, cdouble*, int*, int, hipStream_t, bool);
+template void launch_potrf_diag<float>(float*, int, int, float*, int*, int, hipStream_t, bool, bool, bool);
+template void launch_invert_diag_blocks<float>(const float*, int, int, float*, int*, hipStream_t, bool, bool);
+template void launch_potrf_diag<double>(double*, int, int, double*, int*, int, hipStream_t, bool, bool, bool);
+template void launch_invert_diag_blocks<double>(const double*, int, int, double*, int*, hipStream_t, bool, bool);
+template void launch_potrf_diag<cfloat>(cfloat*, int, int, cfloat*, int*, int, hipStream_t, bool, bool, bool);
+template void launch_invert_diag_blocks<cfloat>(const cfloat*, int, int, cfloat*, int*, hipStream_t, bool, bool);
+template void launch_potrf_diag<cdouble>(cdouble*, int, int, cdouble*, int*, int, hipStream_t, bool, bool, bool);
+template void launch_invert_diag_blocks<cdouble>(const cdouble*, int, int, cdouble*, int*, hipStream_t, bool, bool);
 
 }  // namespace dlaf_mi355x

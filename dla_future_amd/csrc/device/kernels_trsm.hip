@@ -10,6 +10,8 @@
 // "inverted diagonal block" scheme vendor trsm uses).  One read of B, one write of X per strip:
 // algorithmic HBM bytes = (n^2/2 + 2 rows n) sizeof(T) per tile -- this is the kernel whose
 // achieved GB/s is reported next to its n^2 rows flops.
+#include <type_traits>
+
 #include "device_api.hpp"
 #include "mma_core.hpp"
 
@@ -33,7 +35,10 @@ constexpr int trsm_lds_bytes() {
   return Cfg::LDS_BYTES > w ? Cfg::LDS_BYTES : w;
 }
 
-template <class T, bool VEC>
+// UPPER: X U^H = B with U upper triangular: B_j = sum_{p>=j} X_p U_{j,p}^H, so the blocks are swept right to
+// left, the K range of block j is the columns right of it, and inv(U_jj) is upper triangular (the
+// triangular solver's Upper / transposed-Lower variants, solver/triangular/impl.h).
+template <class T, bool VEC, bool UPPER>
 __global__ __launch_bounds__(kThreads, TrsmCfg<T>::min_waves) void trsm_kernel(TrsmArgs<T> p, int spt) {
   using Cfg = typename TrsmCfg<T>::type;
   using R = real_t<T>;
@@ -60,16 +65,22 @@ __global__ __launch_bounds__(kThreads, TrsmCfg<T>::min_waves) void trsm_kernel(T
   const int g = lane >> 4, c = lane & 15;
   const int njb = (p.n + JB - 1) / JB;
 
-  for (int j = 0; j < njb; ++j) {
+  for (int jj = 0; jj < njb; ++jj) {
+    const int j = UPPER ? njb - 1 - jj : jj;
     const int jb = min(JB, p.n - j * JB);
-    const int K = j * JB;
-    const bool full = (mrows == Cfg::BM) && (jb == JB);
+    const int k0 = UPPER ? (j + 1) * JB : 0;            // first column of the already solved part
+    const int K = UPPER ? max(0, p.n - k0) : j * JB;
+    const bool full = (mrows == Cfg::BM) && (jb == JB) && (K % Cfg::BK == 0);
     Acc<Cfg> y;
     y.clear();
-    if (full)
-      gemm_nt_block<Cfg, T, VEC, false>(Bst, p.ldb, mrows, p.l + j * JB, p.ldl, jb, K, lds, y);
-    else
-      gemm_nt_block<Cfg, T, false, true>(Bst, p.ldb, mrows, p.l + j * JB, p.ldl, jb, K, lds, y);
+    if (K > 0) {
+      const T* Xs = Bst + (long) k0 * p.ldb;
+      const T* Lj = p.l + j * JB + (long) k0 * p.ldl;
+      if (full)
+        gemm_nt_block<Cfg, T, VEC, false>(Xs, p.ldb, mrows, Lj, p.ldl, jb, K, lds, y);
+      else
+        gemm_nt_block<Cfg, T, false, true>(Xs, p.ldb, mrows, Lj, p.ldl, jb, K, lds, y);
+    }
 
     // ---- Y = B_j - acc (C layout: lane holds m = wm*32 + i*16 + c, n = j2*16 + irow(g,v)) ------
     T* Bj = Bst + (long) (j * JB) * p.ldb;
@@ -104,7 +115,9 @@ __global__ __launch_bounds__(kThreads, TrsmCfg<T>::min_waves) void trsm_kernel(T
     }
     __syncthreads();
 #pragma unroll
-    for (int j2 = Cfg::TN - 1; j2 >= 0; --j2) {
+    for (int jx = 0; jx < Cfg::TN; ++jx) {
+      // lower W: highest X tile first (Y tile ct feeds X tiles j2 >= ct); upper W: lowest first
+      const int j2 = UPPER ? jx : Cfg::TN - 1 - jx;
       acc_t xre[Cfg::TM], xim[Cfg::TM];
 #pragma unroll
       for (int i = 0; i < Cfg::TM; ++i) {
@@ -112,7 +125,10 @@ __global__ __launch_bounds__(kThreads, TrsmCfg<T>::min_waves) void trsm_kernel(T
         xim[i] = acc_t{0, 0, 0, 0};
       }
 #pragma unroll
-      for (int ct = 0; ct <= j2; ++ct)  // W is lower triangular: W[n2][k] = 0 for k > n2
+      for (int ct = 0; ct < Cfg::TN; ++ct) {
+        // W lower triangular: W[n2][k] = 0 for k > n2;  upper: = 0 for k < n2
+        if (UPPER ? (ct < j2) : (ct > j2))
+          continue;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           // accumulator register v of lane-group g holds k = 16*ct + irow(g, v): read the partner
@@ -133,6 +149,7 @@ __global__ __launch_bounds__(kThreads, TrsmCfg<T>::min_waves) void trsm_kernel(T
             }
           }
         }
+      }
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int nl = j2 * 16 + Mma<R>::irow(g, v);
@@ -166,19 +183,27 @@ void launch_trsm(const TrsmArgs<T>& a, hipStream_t stream) {
   const int spt = (a.nb + Cfg::BM - 1) / Cfg::BM;
   const long grid = (long) (a.il1 - a.il0) * spt;
   const bool vec = aligned16<T>(a.b, a.ldb) && aligned16<T>(a.b, a.b_ts) && aligned16<T>(a.l, a.ldl);
-  if (vec)
-    hipLaunchKernelGGL((trsm_kernel<T, true>), dim3((unsigned) grid), dim3(kThreads), trsm_lds_bytes<T>(), stream, a, spt);
+  auto go = [&](auto vtag, auto utag) {
+    hipLaunchKernelGGL((trsm_kernel<T, decltype(vtag)::value, decltype(utag)::value>), dim3((unsigned) grid),
+                       dim3(kThreads), trsm_lds_bytes<T>(), stream, a, spt);
+  };
+  if (a.upper)
+    vec ? go(std::true_type{}, std::true_type{}) : go(std::false_type{}, std::true_type{});
   else
-    hipLaunchKernelGGL((trsm_kernel<T, false>), dim3((unsigned) grid), dim3(kThreads), trsm_lds_bytes<T>(), stream, a, spt);
+    vec ? go(std::true_type{}, std::false_type{}) : go(std::false_type{}, std::false_type{});
 }
 
 template <class T>
 static void trsm_init_one() {
 
-  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_kernel<T, true>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, trsm_lds_bytes<T>());
-  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_kernel<T, false>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, trsm_lds_bytes<T>());
+#define SET_ONE(V, U)                                                                      \
+  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_kernel<T, V, U>),          \
+                             hipFuncAttributeMaxDynamicSharedMemorySize, trsm_lds_bytes<T>())
+  SET_ONE(true, false);
+  SET_ONE(false, false);
+  SET_ONE(true, true);
+  SET_ONE(false, true);
+#undef SET_ONE
 }
 
 void trsm_kernels_init() {

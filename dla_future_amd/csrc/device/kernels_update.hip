@@ -97,14 +97,14 @@ __device__ __forceinline__ void update_block(const UpdateArgs<T>& p, const Updat
   const int il = p.il0 + br / mp.bpt_m, sbr = br % mp.bpt_m;
   const int jl = p.jl0 + bc / mp.bpt_n, sbc = bc % mp.bpt_n;
   const int gi = il * p.pr + p.ri, gj = jl * p.pc + p.ci;
-  if (gi < gj)
+  if (!p.rect && gi < gj)
     return;
   const int rows_tile = (gi == p.nt - 1) ? p.last_rows : p.nb;
-  const int cols_tile = (gj == p.nt - 1) ? p.last_rows : p.nb;
+  const int cols_tile = p.rect ? ((gj == p.nt_c - 1) ? p.last_cols : p.nb) : ((gj == p.nt - 1) ? p.last_rows : p.nb);
   const int m0 = sbr * Cfg::BM, n0 = sbc * Cfg::BN;
   if (m0 >= rows_tile || n0 >= cols_tile)
     return;
-  const bool diag = (gi == gj);
+  const bool diag = !p.rect && (gi == gj);
   const int mrows = min(Cfg::BM, rows_tile - m0), ncols = min(Cfg::BN, cols_tile - n0);
   if (diag && m0 + mrows - 1 < n0)
     return;  // block strictly above the diagonal of a diagonal tile
@@ -304,7 +304,7 @@ void launch_update(const UpdateArgs<T>& a, hipStream_t stream, int role, long ma
       const int jl_min = a.jl0 + (pj << mp.psc) / mp.bpt_n;
       const long gj_min = (long) jl_min * a.pc + a.ci;
       long il_first = (gj_min - a.ri + a.pr - 1) / a.pr;  // ceil((gj - ri) / pr) for gj >= ri
-      if (gj_min <= a.ri)
+      if (gj_min <= a.ri || a.rect)
         il_first = 0;
       if (il_first < a.il0)
         il_first = a.il0;

@@ -130,6 +130,53 @@ void pxpotrf(char uplo, int n, HT* a, int ia, int ja, const int desca[9], int* i
     *info = r;
 }
 
+// dlaf::triangular_solver (include/dlaf/solver/triangular.h:41-177) through descriptors
+template <class HT>
+int triangular_solver_c(int ctx, char side, char uplo, char op, char diag, const HT* alpha, const HT* a,
+                        const DLAF_descriptor& da, HT* b, const DLAF_descriptor& db) {
+  using DT = typename DevType<HT>::type;
+  auto is = [](char c, const char* set) { return c != 0 && std::strchr(set, c) != nullptr; };
+  if (!is(side, "LlRr") || !is(uplo, "LlUu") || !is(op, "NnTtCc") || !is(diag, "NnUu"))
+    fatal("[dlaf_mi355x] triangular solver: bad side/uplo/op/diag '%c' '%c' '%c' '%c'\n", side, uplo, op, diag);
+  if (da.i != 0 || da.j != 0 || db.i != 0 || db.j != 0)
+    fatal("[dlaf_mi355x] sub-matrices are not supported: offsets must be 0\n");
+  // preconditions of triangular.h:43-48, :57 / :93-98: A square with square blocks, op(A) and B multipliable
+  if (da.m != da.n || da.mb != da.nb || da.nb < 1)
+    fatal("[dlaf_mi355x] triangular solver: A must be square with square blocks (%d x %d, %d x %d)\n", da.m, da.n,
+          da.mb, da.nb);
+  const bool left = (side == 'L' || side == 'l');
+  if (db.m < 0 || db.n < 0 || da.m != (left ? db.m : db.n))
+    fatal("[dlaf_mi355x] triangular solver: A is %d x %d, B is %d x %d (side %c)\n", da.m, da.n, db.m, db.n, side);
+  // this build keeps square nb x nb device tiles: B's blocks must be the blocks of A
+  if (db.mb != da.nb || db.nb != da.nb)
+    fatal("[dlaf_mi355x] triangular solver: B's blocks (%d x %d) must equal A's (%d x %d)\n", db.mb, db.nb, da.mb,
+          da.nb);
+  Grid& g = grid_from_context(ctx);
+  for (const DLAF_descriptor* d : {&da, &db})
+    if (d->isrc < 0 || d->isrc >= g.nprow || d->jsrc < 0 || d->jsrc >= g.npcol)
+      fatal("[dlaf_mi355x] source rank (%d,%d) outside the %d x %d grid\n", d->isrc, d->jsrc, g.nprow, g.npcol);
+  DT al;
+  std::memcpy(&al, alpha, sizeof(DT));
+  return triangular_solver_host<DT>(&g, side, uplo, op, diag, al, reinterpret_cast<const DT*>(a), da.ld, da.isrc,
+                                    da.jsrc, reinterpret_cast<DT*>(b), db.ld, db.m, db.n, da.nb, db.isrc, db.jsrc);
+}
+
+// ScaLAPACK p?trsm argument list
+template <class HT>
+void pxtrsm(char side, char uplo, char op, char diag, int m, int n, const HT* alpha, const HT* a, int ia, int ja,
+            const int desca[9], HT* b, int ib, int jb, const int descb[9]) {
+  if (desca[0] != 1 || descb[0] != 1)
+    fatal("[dlaf_mi355x] desc[0] (dtype) must be 1\n");
+  if (ia != 1 || ja != 1 || ib != 1 || jb != 1)
+    fatal("[dlaf_mi355x] ia, ja, ib, jb must be 1\n");
+  if (desca[1] != descb[1])
+    fatal("[dlaf_mi355x] A and B live on different contexts (%d, %d)\n", desca[1], descb[1]);
+  const int na = (side == 'L' || side == 'l') ? m : n;
+  const DLAF_descriptor da = make_dlaf_descriptor(na, na, ia, ja, desca);
+  const DLAF_descriptor db = make_dlaf_descriptor(m, n, ib, jb, descb);
+  (void) triangular_solver_c<HT>(desca[1], side, uplo, op, diag, alpha, a, da, b, db);
+}
+
 struct MatrixHandle {
   std::unique_ptr<MatrixBase> m;
   char type;
@@ -298,6 +345,23 @@ int dlaf_mi355x_grid_host_bcast(int ctx, int axis, int root, void* host_buf, siz
     return g.nranks == 1 ? 0 : -2;
   return g.host_bcast(g.host_user, axis, root, host_buf, bytes);
 }
+
+#define DLAF_MI355X_TRSM_ENTRY(S, HT, CT)                                                                        \
+  int dlaf_mi355x_triangular_solver_##S(int ctx, char side, char uplo, char op, char diag, const CT* alpha,      \
+                                        const CT* a, DLAF_descriptor desca, CT* b, DLAF_descriptor descb) noexcept { \
+    return triangular_solver_c<HT>(ctx, side, uplo, op, diag, reinterpret_cast<const HT*>(alpha),               \
+                                   reinterpret_cast<const HT*>(a), desca, reinterpret_cast<HT*>(b), descb);     \
+  }                                                                                                             \
+  void dlaf_mi355x_p##S##trsm(char side, char uplo, char op, char diag, int m, int n, const CT* alpha, const CT* a, \
+                              int ia, int ja, const int desca[9], CT* b, int ib, int jb, const int descb[9]) noexcept { \
+    pxtrsm<HT>(side, uplo, op, diag, m, n, reinterpret_cast<const HT*>(alpha), reinterpret_cast<const HT*>(a), ia, \
+               ja, desca, reinterpret_cast<HT*>(b), ib, jb, descb);                                              \
+  }
+DLAF_MI355X_TRSM_ENTRY(s, float, float)
+DLAF_MI355X_TRSM_ENTRY(d, double, double)
+DLAF_MI355X_TRSM_ENTRY(c, std::complex<float>, dlaf_complex_c)
+DLAF_MI355X_TRSM_ENTRY(z, std::complex<double>, dlaf_complex_z)
+#undef DLAF_MI355X_TRSM_ENTRY
 
 int dlaf_mi355x_matrix_create(int ctx, char type, char uplo, DLAF_descriptor d, dlaf_mi355x_matrix_t* out) noexcept {
   if (!out)

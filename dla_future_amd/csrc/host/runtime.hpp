@@ -153,6 +153,12 @@ void tile_gemm(char uplo, int m, int n, int k, const T* a, int lda, const T* b, 
 // factorization issues), then barrier + max-allreduce.  Returns the number of mismatching checks.
 int grid_selftest(Grid& g, size_t bytes);
 
+// op(A) X = alpha B (side L) / X op(A) = alpha B (side R) on the grid, host operands (solver.cpp);
+// m x n: size of B, nb: the square block of A and B
+template <class T>
+int triangular_solver_host(Grid* g, char side, char uplo, char op, char diag, T alpha, const T* a, long lda, int a_isrc,
+                           int a_jsrc, T* b, long ldb, long m, long n, int nb, int b_isrc, int b_jsrc);
+
 void runtime_init();
 void runtime_finalize();
 bool runtime_initialized();

@@ -1,0 +1,535 @@
+// solver.cpp -- distributed triangular solve  op(A) X = alpha B  /  X op(A) = alpha B  on the tile kernels
+// of the Cholesky path.
+//
+// Reference: dlaf::triangular_solver (include/dlaf/solver/triangular.h:41-177) and its eight hand-written
+// variants call_{L,R}{L,U}{N,T} (solver/triangular/impl.h), each with its own tile loop and communication
+// pattern (broadcasts for the NoTrans variants, reductions for the transposed ones).
+//
+// MI355X design: ONE device algorithm, the one the Cholesky kernels already implement,
+//
+//        X * T^H = B        T triangular (lower: swept forward, upper: swept backward)
+//
+//   step k:  X(:,k)  = B(:,k) * T_kk^-H                  panel TRSM kernel (inverted diagonal blocks)
+//            B(:,j) -= X(:,k) * T(j,k)^H   for j beyond k   grouped NT update kernel, rectangular mode
+//
+// and every side / uplo / op / diag / alpha combination is mapped onto it when the operands are laid out
+// on the device (the relayout kernel transposes, conjugates and scales on the way):
+//
+//   Right, op = C :  X A^H = aB            T = A            B_dev = a B
+//   Right, op = N :  X A   = aB            T = A^H          B_dev = a B
+//   Right, op = T :  X A^T = aB            T = conj(A)      B_dev = a B
+//   Left,  op = N :  A X   = aB  <=>  X^H A^H   = (aB)^H    T = A            B_dev = (a B)^H
+//   Left,  op = C :  A^H X = aB  <=>  X^H A     = (aB)^H    T = A^H          B_dev = (a B)^H
+//   Left,  op = T :  A^T X = aB  <=>  X^H conj(A) = (aB)^H  T = A^T          B_dev = (a B)^H
+//
+// A transposed view of a block-cyclic matrix needs no communication: tile (i,j) of the view is tile (j,i)
+// of the caller's matrix and stays on the same process, with the roles of process rows and columns swapped
+// (the same device the Cholesky uses for uplo = U).  Two communication shapes remain, depending on whether
+// T's rows are spread over the same grid dimension as B_dev's columns ("aligned": one broadcast of T's
+// column panel) or over the other one ("crossed": the Cholesky's panel + transposed-panel pair).  T's
+// panels depend on A only, so they are broadcast one step ahead of the sweep.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "runtime.hpp"
+
+namespace dlaf_mi355x {
+
+namespace {
+
+template <class T>
+T* dev_alloc(size_t elems) {
+  T* p = nullptr;
+  if (elems == 0)
+    elems = 1;
+  DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), elems * sizeof(T)));
+  return p;
+}
+
+// General block-cyclic matrix in device tile layout (nb x nb tiles, tile (il,jl) at (il + jl*ltr) nb^2).
+template <class T>
+struct TileMatrix {
+  Grid* grid = nullptr;
+  bool transposed = false;  // the view is the (conjugate-)transpose of the caller's matrix
+  Axis rows, cols;          // axes of the VIEW
+  int nb = 1;
+  long ltr = 0, ltc = 0;
+  size_t tile_elems = 0;
+  T* tiles = nullptr;
+  T* staging = nullptr;
+
+  // m_src x n_src: global size of the caller's matrix, (isrc, jsrc) its source process
+  void create(Grid* g, bool transposed_, long m_src, long n_src, int nb_, int isrc, int jsrc) {
+    grid = g;
+    transposed = transposed_;
+    nb = nb_;
+    Axis srow{m_src, nb, g->nprow, g->myrow, isrc};
+    Axis scol{n_src, nb, g->npcol, g->mycol, jsrc};
+    rows = transposed ? scol : srow;
+    cols = transposed ? srow : scol;
+    ltr = rows.local_tiles();
+    ltc = cols.local_tiles();
+    tile_elems = (size_t) nb * nb;
+    tiles = dev_alloc<T>((size_t) ltr * ltc * tile_elems);
+  }
+  ~TileMatrix() {
+    if (tiles)
+      (void) hipFree(tiles);
+    if (staging)
+      (void) hipFree(staging);
+  }
+  T* tile(long il, long jl) const { return tiles + (size_t) (il + jl * ltr) * tile_elems; }
+  // physical grid dimension (0: process rows, 1: process columns) the view's rows / columns are spread over
+  int row_dim() const { return transposed ? 1 : 0; }
+  int col_dim() const { return transposed ? 0 : 1; }
+
+  LayoutArgs<T> layout(T* cm, long ld) const {
+    LayoutArgs<T> a;
+    a.tiles = tiles;
+    a.cm = cm;
+    a.ld_cm = ld;
+    a.ltr = (int) ltr;
+    a.ltc = (int) ltc;
+    a.nb = nb;
+    a.rows = rows.local_size();
+    a.cols = cols.local_size();
+    a.pr = rows.P;
+    a.ri = rows.shift();
+    a.pc = cols.P;
+    a.ci = cols.shift();
+    a.transpose = transposed ? 1 : 0;
+    a.full = 1;
+    return a;
+  }
+  void source_extents(long& srows, long& scols) const {
+    srows = transposed ? cols.local_size() : rows.local_size();
+    scols = transposed ? rows.local_size() : cols.local_size();
+  }
+  void upload(const T* host, long ld, bool conj, bool scale, T alpha, hipStream_t s) {
+    long srows, scols;
+    source_extents(srows, scols);
+    if (srows == 0 || scols == 0)
+      return;
+    if (!staging)
+      staging = dev_alloc<T>((size_t) srows * scols);
+    DLAF_HIP_CHECK(hipMemcpy2DAsync(staging, (size_t) srows * sizeof(T), host, (size_t) ld * sizeof(T),
+                                    (size_t) srows * sizeof(T), (size_t) scols, hipMemcpyHostToDevice, s));
+    LayoutArgs<T> a = layout(staging, srows);
+    a.conj = conj ? 1 : 0;
+    a.scale = scale ? 1 : 0;
+    a.alpha = alpha;
+    launch_to_tiles(a, s);
+  }
+  void download(T* host, long ld, bool conj, hipStream_t s) {
+    long srows, scols;
+    source_extents(srows, scols);
+    if (srows == 0 || scols == 0)
+      return;
+    if (!staging)
+      staging = dev_alloc<T>((size_t) srows * scols);
+    LayoutArgs<T> a = layout(staging, srows);
+    a.conj = conj ? 1 : 0;
+    launch_from_tiles(a, s);
+    DLAF_HIP_CHECK(hipMemcpy2DAsync(host, (size_t) ld * sizeof(T), staging, (size_t) srows * sizeof(T),
+                                    (size_t) srows * sizeof(T), (size_t) scols, hipMemcpyDeviceToHost, s));
+  }
+};
+
+template <class T>
+T conj_el(T v) {
+  if constexpr (TypeInfo<T>::is_complex)
+    v.im = -v.im;
+  return v;
+}
+
+struct Events {
+  std::vector<hipEvent_t> v;
+  explicit Events(size_t n) : v(n) {
+    for (auto& e : v)
+      DLAF_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  ~Events() {
+    for (auto e : v)
+      (void) hipEventDestroy(e);
+  }
+  hipEvent_t operator[](size_t i) const { return v[i]; }
+};
+
+// X T^H = B in place on Bd; Td lower (swept forward) or upper (swept backward) triangular, unit: its
+// diagonal is taken as 1.  Both operands on the same grid; Td's index distribution along the grid dimension
+// it shares with Bd's columns must be the one of Bd's columns (checked by the caller).
+template <class T>
+void solve_canonical(TileMatrix<T>& Td, TileMatrix<T>& Bd, bool upper, bool unit) {
+  Grid* g = Bd.grid;
+  Transport* tr = g->transport.get();
+  const bool dist = g->nranks > 1;
+  const int nb = Bd.nb;
+  const long nt = Bd.cols.nt();  // tiles along n
+  if (nt == 0 || Bd.rows.nt() == 0)
+    return;
+  const size_t tile_elems = Bd.tile_elems, tile_bytes = tile_elems * sizeof(T);
+  const size_t winv_elems = (size_t) ((nb + kDiagBlock - 1) / kDiagBlock) * kDiagBlock * kDiagBlock;
+  const size_t diag_elems = tile_elems + winv_elems;
+
+  // communicators seen from Bd's view: along its rows (members differ in view-column coordinate) and
+  // along its columns
+  const CommAxis along_row = Bd.transposed ? CommAxis::Col : CommAxis::Row;
+  const CommAxis along_col = Bd.transposed ? CommAxis::Row : CommAxis::Col;
+  // aligned: Td's rows live on the grid dimension of Bd's columns; crossed: on the one of Bd's rows
+  const bool aligned = Td.row_dim() == Bd.col_dim();
+  const Axis& t_match = aligned ? Td.rows : Td.cols;  // Td axis that shares Bd.cols' dimension
+  const Axis& t_other = aligned ? Td.cols : Td.rows;  // ... and the one that shares Bd.rows' dimension
+  if (t_match.P != Bd.cols.P || t_match.src != Bd.cols.src || t_match.n != Bd.cols.n)
+    fatal("[dlaf_mi355x] triangular solver: A and B are not aligned along the triangular dimension "
+          "(source process %d vs %d)\n", t_match.src, Bd.cols.src);
+
+  hipStream_t s_main = nullptr, s_comm = nullptr;
+  int lo = 0, hi = 0;
+  DLAF_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  DLAF_HIP_CHECK(hipStreamCreateWithPriority(&s_main, hipStreamNonBlocking, lo));
+  DLAF_HIP_CHECK(hipStreamCreateWithPriority(&s_comm, hipStreamNonBlocking, hi));
+  Events ev_t((size_t) nt), ev_x((size_t) nt), ev_xb((size_t) nt), ev_free((size_t) nt);
+
+  int* info = nullptr;
+  DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&info), sizeof(int)));
+  DLAF_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int), s_main));
+
+  // ---- preparation: inverted 64 x 64 diagonal blocks of every local diagonal tile of Td ---------------
+  std::vector<long> my_diag;  // global indices of the diagonal tiles I own
+  for (long k = 0; k < nt; ++k)
+    if (Td.rows.mine(k) && Td.cols.mine(k))
+      my_diag.push_back(k);
+  T* winv_all = dev_alloc<T>(my_diag.size() * winv_elems);
+  DLAF_HIP_CHECK(hipMemsetAsync(winv_all, 0, std::max<size_t>(1, my_diag.size() * winv_elems) * sizeof(T), s_main));
+  for (size_t q = 0; q < my_diag.size(); ++q) {
+    const long k = my_diag[q];
+    launch_invert_diag_blocks(Td.tile(Td.rows.local_of(k), Td.cols.local_of(k)), nb, Td.rows.tile_extent(k),
+                              winv_all + q * winv_elems, info, s_main, upper, unit);
+  }
+  hipEvent_t ev_prep;
+  DLAF_HIP_CHECK(hipEventCreateWithFlags(&ev_prep, hipEventDisableTiming));
+  DLAF_HIP_CHECK(hipEventRecord(ev_prep, s_main));
+  DLAF_HIP_CHECK(hipStreamWaitEvent(s_comm, ev_prep, 0));
+
+  // workspaces, kBuf of each (step s uses s % kBuf; the T operands of step s+1 are fetched while step s-1 is
+  // still being applied): [T_kk | W_k], the T column panel as the update's second operand (one tile per
+  // local column of Bd), its staging for the crossed shape, the X panel on non-owners
+  constexpr int kBuf = 3;
+  T* diag_ws[kBuf] = {nullptr, nullptr, nullptr};
+  T* tpanel[kBuf] = {nullptr, nullptr, nullptr};
+  T* tstage[kBuf] = {nullptr, nullptr, nullptr};
+  T* xpanel[kBuf] = {nullptr, nullptr, nullptr};
+  for (int b = 0; b < kBuf; ++b) {
+    diag_ws[b] = dev_alloc<T>(diag_elems);
+    if (dist) {
+      tpanel[b] = dev_alloc<T>((size_t) Bd.ltc * tile_elems);
+      if (!aligned)
+        tstage[b] = dev_alloc<T>((size_t) Td.ltr * tile_elems);
+      xpanel[b] = dev_alloc<T>((size_t) Bd.ltr * tile_elems);
+    }
+  }
+
+  // global step order and the set of columns "beyond" step k
+  auto step_k = [&](long s) { return upper ? nt - 1 - s : s; };
+
+  struct TOperand {
+    const T* diag = nullptr;  // T_kk
+    const T* winv = nullptr;  // its inverted diagonal blocks
+    const T* base = nullptr;  // T(j,k) for local column jl of Bd at base + (jl - jl0) * ts
+    long ts = 0;
+    long jl0 = 0, jl1 = 0;    // local columns of Bd beyond step k
+  };
+  std::vector<TOperand> top((size_t) nt);
+
+  // ---- s_comm: everything the step needs of T (depends on A only: issued ahead of the sweep) ----------
+  auto fetch_t = [&](long s) {
+    const long k = step_k(s);
+    const int buf = (int) (s % kBuf);
+    TOperand& o = top[(size_t) s];
+    // local columns of Bd beyond k
+    o.jl0 = upper ? 0 : Bd.cols.next_local(k + 1);
+    o.jl1 = upper ? Bd.cols.next_local(k) : Bd.ltc;
+    // these buffers were last read by the kernels of step s - kBuf (event recorded before this call is made)
+    if (s >= kBuf)
+      DLAF_HIP_CHECK(hipStreamWaitEvent(s_comm, ev_free[(size_t) (s - kBuf)], 0));
+
+    // (1) T_kk and its inverted diagonal blocks to every process holding column k of Bd
+    const bool own_diag = Td.rows.mine(k) && Td.cols.mine(k);
+    const bool need_diag = Bd.cols.mine(k);
+    const T* tkk = nullptr;
+    const T* wk = nullptr;
+    if (own_diag) {
+      const size_t q = (size_t) (std::find(my_diag.begin(), my_diag.end(), k) - my_diag.begin());
+      tkk = Td.tile(Td.rows.local_of(k), Td.cols.local_of(k));
+      wk = winv_all + q * winv_elems;
+    }
+    if (need_diag && Bd.rows.P > 1) {
+      // (own_diag implies need_diag: the owner sits in Bd's column k by the alignment requirement)
+      if (own_diag) {
+        DLAF_HIP_CHECK(hipMemcpyAsync(diag_ws[buf], tkk, tile_bytes, hipMemcpyDeviceToDevice, s_comm));
+        DLAF_HIP_CHECK(hipMemcpyAsync(diag_ws[buf] + tile_elems, wk, winv_elems * sizeof(T), hipMemcpyDeviceToDevice, s_comm));
+      }
+      tr->bcast(along_col, t_other.owner(k), Bd.rows.rank, diag_ws[buf], diag_ws[buf], diag_elems * sizeof(T), s_comm);
+      tkk = diag_ws[buf];
+      wk = diag_ws[buf] + tile_elems;
+    }
+    o.diag = tkk;
+    o.winv = wk;
+
+    // (2) T(j,k) for the local columns j of Bd beyond k
+    const long ncols = o.jl1 - o.jl0;
+    if (!dist) {
+      // one process: Td's local row index of global j is Bd's local column index
+      o.base = Td.tile(o.jl0 < Td.ltr ? o.jl0 : 0, k);
+      o.ts = (long) tile_elems;
+    }
+    else if (aligned) {
+      // Td's rows are spread like Bd's columns: the tiles sit on the process of the same Bd-column
+      // coordinate whose Bd-row coordinate owns Td's column k -> one broadcast along Bd's columns
+      const bool have = t_other.mine(k);
+      T* dst = tpanel[buf];
+      if (ncols > 0) {
+        const T* src = have ? Td.tile(o.jl0, Td.cols.local_of(k)) : nullptr;
+        if (Bd.rows.P > 1)
+          tr->bcast(along_col, t_other.owner(k), Bd.rows.rank, src, dst, (size_t) ncols * tile_bytes, s_comm);
+        else
+          dst = const_cast<T*>(src);
+      }
+      o.base = dst;
+      o.ts = (long) tile_elems;
+    }
+    else {
+      // crossed: Td's rows are spread like Bd's ROWS.  Column panel k of Td along Bd's rows first, then
+      // tile j down Bd's columns from the Bd-row coordinate that owns Td's row j (broadcast_panel.h:125-210)
+      const long il0 = upper ? 0 : Td.rows.next_local(k + 1);
+      const long il1 = upper ? Td.rows.next_local(k) : Td.ltr;
+      const bool have = Td.cols.mine(k);
+      const T* colp = nullptr;  // my rows [il0, il1) of Td's column k
+      if (il1 > il0) {
+        if (Bd.cols.P > 1) {
+          const T* src = have ? Td.tile(il0, Td.cols.local_of(k)) : nullptr;
+          tr->bcast(along_row, Td.cols.owner(k), Bd.cols.rank, src, tstage[buf], (size_t) (il1 - il0) * tile_bytes, s_comm);
+          colp = tstage[buf];
+        }
+        else {
+          colp = Td.tile(il0, Td.cols.local_of(k));
+        }
+      }
+      if (Bd.rows.P > 1) {
+        tr->group_begin();
+        for (long jl = o.jl0; jl < o.jl1; ++jl) {
+          const long gj = Bd.cols.global_of(jl);
+          const int root = Td.rows.owner(gj);
+          const T* src = (Td.rows.rank == root) ? colp + (size_t) (Td.rows.local_of(gj) - il0) * tile_elems : nullptr;
+          tr->bcast(along_col, root, Bd.rows.rank, src, tpanel[buf] + (size_t) (jl - o.jl0) * tile_elems, tile_bytes, s_comm);
+        }
+        tr->group_end();
+        o.base = tpanel[buf];
+        o.ts = (long) tile_elems;
+      }
+      else {
+        // I hold every row of Td's column k: tile gj sits at local row gj
+        o.base = colp ? colp + (size_t) (Bd.cols.global_of(o.jl0 < Bd.ltc ? o.jl0 : 0) - il0) * tile_elems : nullptr;
+        o.ts = (long) tile_elems * Bd.cols.P;
+      }
+    }
+    DLAF_HIP_CHECK(hipEventRecord(ev_t[(size_t) s], s_comm));
+  };
+
+  auto update = [&](long s, const T* xp, long j0, long j1) {
+    const TOperand& o = top[(size_t) s];
+    j0 = std::max(j0, o.jl0);
+    j1 = std::min(j1, o.jl1);
+    if (j0 >= j1 || Bd.ltr == 0)
+      return;
+    const long k = step_k(s);
+    UpdateArgs<T> ua;
+    ua.c = Bd.tiles;
+    ua.c_tsr = (long) tile_elems;
+    ua.c_tsc = (long) (tile_elems * Bd.ltr);
+    ua.ldc = nb;
+    ua.a = xp;
+    ua.a_ts = (long) tile_elems;
+    ua.lda = nb;
+    ua.b = o.base + (j0 - o.jl0) * o.ts;
+    ua.b_ts = o.ts;
+    ua.ldb = nb;
+    ua.il0 = 0;
+    ua.il1 = (int) Bd.ltr;
+    ua.jl0 = (int) j0;
+    ua.jl1 = (int) j1;
+    ua.nb = nb;
+    ua.K = Bd.cols.tile_extent(k);
+    ua.pr = Bd.rows.P;
+    ua.ri = Bd.rows.shift();
+    ua.pc = Bd.cols.P;
+    ua.ci = Bd.cols.shift();
+    ua.nt = (int) Bd.rows.nt();
+    ua.last_rows = Bd.rows.last_extent();
+    ua.rect = 1;
+    ua.nt_c = (int) nt;
+    ua.last_cols = Bd.cols.last_extent();
+    ua.info = info;
+    launch_update(ua, s_main, 0);
+  };
+
+  // ---- the sweep --------------------------------------------------------------------------------------
+  // s_main: TRSM(s) . U(s, next column) . TRSM(s+1) . U(s, the rest) . U(s+1, next column) ...  so that the
+  // X panel of step s+1 is on the wire under the bulk of step s; T operands arrive one step ahead on s_comm
+  fetch_t(0);
+  const T* xp_prev = nullptr;
+  for (long s = 0; s < nt; ++s) {
+    const long k = step_k(s);
+    const int buf = (int) (s % kBuf);
+    if (s + 1 < nt)
+      fetch_t(s + 1);
+    DLAF_HIP_CHECK(hipStreamWaitEvent(s_main, ev_t[(size_t) s], 0));
+
+    // column k of Bd: X(:,k) = B(:,k) T_kk^-H
+    const bool in_col = Bd.cols.mine(k);
+    const long klc = in_col ? Bd.cols.local_of(k) : -1;
+    if (in_col && Bd.ltr > 0) {
+      TrsmArgs<T> ta;
+      ta.b = Bd.tile(0, klc);
+      ta.b_ts = (long) tile_elems;
+      ta.ldb = nb;
+      ta.il0 = 0;
+      ta.il1 = (int) Bd.ltr;
+      ta.pr = Bd.rows.P;
+      ta.ri = Bd.rows.shift();
+      ta.nb = nb;
+      ta.nt = (int) Bd.rows.nt();
+      ta.last_rows = Bd.rows.last_extent();
+      ta.l = top[(size_t) s].diag;
+      ta.ldl = nb;
+      ta.winv = top[(size_t) s].winv;
+      ta.n = Bd.cols.tile_extent(k);
+      ta.info = info;
+      ta.upper = upper ? 1 : 0;
+      launch_trsm(ta, s_main);
+    }
+    DLAF_HIP_CHECK(hipEventRecord(ev_x[(size_t) s], s_main));
+
+    // the solved panel to the other members of my Bd row
+    const T* xp = in_col ? Bd.tile(0, klc) : nullptr;
+    if (Bd.cols.P > 1) {
+      DLAF_HIP_CHECK(hipStreamWaitEvent(s_comm, ev_x[(size_t) s], 0));
+      T* dst = in_col ? Bd.tile(0, klc) : xpanel[buf];
+      if (Bd.ltr > 0)
+        tr->bcast(along_row, Bd.cols.owner(k), Bd.cols.rank, dst, dst, (size_t) Bd.ltr * tile_bytes, s_comm);
+      xp = dst;
+      DLAF_HIP_CHECK(hipEventRecord(ev_xb[(size_t) s], s_comm));
+    }
+
+    // what is left of the previous step's update runs under that broadcast
+    if (s >= 1) {
+      const long kn = k;  // the "next column" of step s-1 is this step's column
+      const long jn = Bd.cols.mine(kn) ? Bd.cols.local_of(kn) : -1;
+      if (jn >= 0) {
+        update(s - 1, xp_prev, 0, jn);
+        update(s - 1, xp_prev, jn + 1, Bd.ltc);
+      }
+      else {
+        update(s - 1, xp_prev, 0, Bd.ltc);
+      }
+      DLAF_HIP_CHECK(hipEventRecord(ev_free[(size_t) (s - 1)], s_main));
+    }
+    if (Bd.cols.P > 1)
+      DLAF_HIP_CHECK(hipStreamWaitEvent(s_main, ev_xb[(size_t) s], 0));
+
+    // lookahead: the column the next step solves
+    if (s + 1 < nt) {
+      const long kn = step_k(s + 1);
+      if (Bd.cols.mine(kn)) {
+        const long jn = Bd.cols.local_of(kn);
+        update(s, xp, jn, jn + 1);
+      }
+    }
+    xp_prev = xp;
+  }
+  // the last step has nothing beyond it; its event only releases the buffers
+  DLAF_HIP_CHECK(hipEventRecord(ev_free[(size_t) (nt - 1)], s_main));
+
+  DLAF_HIP_CHECK(hipStreamSynchronize(s_comm));
+  DLAF_HIP_CHECK(hipStreamSynchronize(s_main));
+  (void) hipEventDestroy(ev_prep);
+  (void) hipStreamDestroy(s_main);
+  (void) hipStreamDestroy(s_comm);
+  (void) hipFree(info);
+  (void) hipFree(winv_all);
+  for (int b = 0; b < kBuf; ++b) {
+    (void) hipFree(diag_ws[b]);
+    if (tpanel[b])
+      (void) hipFree(tpanel[b]);
+    if (tstage[b])
+      (void) hipFree(tstage[b]);
+    if (xpanel[b])
+      (void) hipFree(xpanel[b]);
+  }
+}
+
+}  // namespace
+
+// Host entry: a (local part of the triangular matrix, column-major lda), b (local part of the m x n right-hand
+// sides, ldb) on the grid; b is overwritten by the solution.
+template <class T>
+int triangular_solver_host(Grid* g, char side, char uplo, char op, char diag, T alpha, const T* a, long lda, int a_isrc,
+                           int a_jsrc, T* b, long ldb, long m, long n, int nb, int b_isrc, int b_jsrc) {
+  runtime_init();
+  if (g->nranks > 1 && !g->transport && g->host_bcast)
+    g->transport = make_host_transport(g->host_bcast, g->host_barrier, g->host_user);
+  if (g->nranks > 1 && !g->transport)
+    fatal("[dlaf_mi355x] grid with %d ranks has no transport\n", g->nranks);
+  if (m == 0 || n == 0)
+    return 0;
+  const bool left = (side == 'L' || side == 'l');
+  const bool a_upper = (uplo == 'U' || uplo == 'u');
+  const char o = (op == 'n') ? 'N' : (op == 't') ? 'T' : (op == 'c') ? 'C' : op;
+  const bool unit = (diag == 'U' || diag == 'u');
+  const long na = left ? m : n;
+  if (left ? (a_isrc != b_isrc) : (a_jsrc != b_jsrc))
+    fatal("[dlaf_mi355x] triangular solver: A and B must share the source process along the triangular "
+          "dimension\n");
+
+  // T = A (Right C / Left N), A^H (Right N / Left C), conj(A) (Right T), A^T (Left T)
+  bool t_transposed, t_conj;
+  if (left) {
+    t_transposed = (o != 'N');
+    t_conj = (o == 'C');
+  }
+  else {
+    t_transposed = (o == 'N');
+    t_conj = (o == 'N' || o == 'T');
+  }
+  const bool t_upper = a_upper != t_transposed;
+
+  hipStream_t s = nullptr;
+  DLAF_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  {
+    TileMatrix<T> Td, Bd;
+    Td.create(g, t_transposed, na, na, nb, a_isrc, a_jsrc);
+    Bd.create(g, left, m, n, nb, b_isrc, b_jsrc);
+    Td.upload(a, lda, t_conj, false, T{}, s);
+    // Left: B_dev = (alpha B)^H = conj(alpha) B^H (the relayout conjugates first, then scales)
+    Bd.upload(b, ldb, left, true, left ? conj_el(alpha) : alpha, s);
+    DLAF_HIP_CHECK(hipStreamSynchronize(s));
+    solve_canonical(Td, Bd, t_upper, unit);
+    Bd.download(b, ldb, left, s);
+    DLAF_HIP_CHECK(hipStreamSynchronize(s));
+  }
+  DLAF_HIP_CHECK(hipStreamDestroy(s));
+  return 0;
+}
+
+template int triangular_solver_host<float>(Grid*, char, char, char, char, float, const float*, long, int, int, float*,
+                                           long, long, long, int, int, int);
+template int triangular_solver_host<double>(Grid*, char, char, char, char, double, const double*, long, int, int,
+                                            double*, long, long, long, int, int, int);
+template int triangular_solver_host<cfloat>(Grid*, char, char, char, char, cfloat, const cfloat*, long, int, int,
+                                            cfloat*, long, long, long, int, int, int);
+template int triangular_solver_host<cdouble>(Grid*, char, char, char, char, cdouble, const cdouble*, long, int, int,
+                                             cdouble*, long, long, long, int, int, int);
+
+}  // namespace dlaf_mi355x

@@ -84,6 +84,44 @@ DLAF_EXTERN_C int dlaf_mi355x_grid_barrier(int context) DLAF_NOEXCEPT;
  * DLAF_MI355X_RCCL_SINGLE=1 makes create_grid_rccl build communicators for a 1-process grid too. */
 DLAF_EXTERN_C int dlaf_mi355x_grid_selftest(int context, size_t bytes) DLAF_NOEXCEPT;
 
+/* ---- triangular solver ------------------------------------------------------- */
+/* dlaf::triangular_solver(grid, side, uplo, op, diag, alpha, A, B), include/dlaf/solver/triangular.h:41-177
+ * (the reference has no C entry for it; the p?trsm names take ScaLAPACK's argument list):
+ *   side 'L': op(A) X = alpha B,  side 'R': X op(A) = alpha B;  B (m x n) is overwritten by X.
+ * A: na x na triangular (na = m for 'L', n for 'R'), only the uplo triangle is read (diag 'U': its diagonal
+ * is taken as 1), op in N/T/C, alpha passed by address.  a, b: local column-major parts on the grid of
+ * `context`.  Requirements of this build: square blocks, B's block = A's block, no sub-matrix offsets, A and
+ * B share the source process along the triangular dimension.  Returns 0; bad arguments terminate like the
+ * reference's DLAF_ASSERTs. */
+DLAF_EXTERN_C int dlaf_mi355x_triangular_solver_s(int context, char side, char uplo, char op, char diag,
+                                                  const float* alpha, const float* a, struct DLAF_descriptor desca,
+                                                  float* b, struct DLAF_descriptor descb) DLAF_NOEXCEPT;
+DLAF_EXTERN_C int dlaf_mi355x_triangular_solver_d(int context, char side, char uplo, char op, char diag,
+                                                  const double* alpha, const double* a, struct DLAF_descriptor desca,
+                                                  double* b, struct DLAF_descriptor descb) DLAF_NOEXCEPT;
+DLAF_EXTERN_C int dlaf_mi355x_triangular_solver_c(int context, char side, char uplo, char op, char diag,
+                                                  const dlaf_complex_c* alpha, const dlaf_complex_c* a,
+                                                  struct DLAF_descriptor desca, dlaf_complex_c* b,
+                                                  struct DLAF_descriptor descb) DLAF_NOEXCEPT;
+DLAF_EXTERN_C int dlaf_mi355x_triangular_solver_z(int context, char side, char uplo, char op, char diag,
+                                                  const dlaf_complex_z* alpha, const dlaf_complex_z* a,
+                                                  struct DLAF_descriptor desca, dlaf_complex_z* b,
+                                                  struct DLAF_descriptor descb) DLAF_NOEXCEPT;
+DLAF_EXTERN_C void dlaf_mi355x_pstrsm(char side, char uplo, char op, char diag, int m, int n, const float* alpha,
+                                      const float* a, int ia, int ja, const int desca[9], float* b, int ib, int jb,
+                                      const int descb[9]) DLAF_NOEXCEPT;
+DLAF_EXTERN_C void dlaf_mi355x_pdtrsm(char side, char uplo, char op, char diag, int m, int n, const double* alpha,
+                                      const double* a, int ia, int ja, const int desca[9], double* b, int ib, int jb,
+                                      const int descb[9]) DLAF_NOEXCEPT;
+DLAF_EXTERN_C void dlaf_mi355x_pctrsm(char side, char uplo, char op, char diag, int m, int n,
+                                      const dlaf_complex_c* alpha, const dlaf_complex_c* a, int ia, int ja,
+                                      const int desca[9], dlaf_complex_c* b, int ib, int jb,
+                                      const int descb[9]) DLAF_NOEXCEPT;
+DLAF_EXTERN_C void dlaf_mi355x_pztrsm(char side, char uplo, char op, char diag, int m, int n,
+                                      const dlaf_complex_z* alpha, const dlaf_complex_z* a, int ia, int ja,
+                                      const int desca[9], dlaf_complex_z* b, int ib, int jb,
+                                      const int descb[9]) DLAF_NOEXCEPT;
+
 /* ---- synthetic input ------------------------------------------------------------------------ */
 /* Fills this process's local array (column-major, ld) of the n x n matrix with the reference's
  * random Hermitian positive definite matrix: per global tile a std::mt19937_64 seeded with the

@@ -314,6 +314,52 @@ def omp_max_threads() -> int:
 
 
 # ----------------------------------------------------------------------------- checker
+def _polar(dt, r, theta):
+    """TypeUtilities<T>::polar (test/include/dlaf_test/util_types.h): r for real types, r e^{i theta} for complex"""
+    if np.dtype(dt).kind == "c":
+        return np.dtype(dt).type(r * np.cos(theta) + 1j * r * np.sin(theta))
+    return np.dtype(dt).type(r)
+
+
+def triangular_system(side: str, uplo: str, op: str, diag: str, alpha, m: int, n: int, dtype):
+    """getTriangularSystem (test/include/dlaf_test/matrix/util_generic_blas.h:258-373): returns (A, B, X) with
+    op(A) X = alpha B (side L) or X op(A) = alpha B (side R).  A holds -9.9 outside the referenced triangle and
+    on a unit diagonal, exactly as the reference's generator stores it."""
+    dt = np.dtype(dtype).type
+    alpha = dt(alpha)
+    op_a_lower = (uplo == "L" and op == "N") or (uplo == "U" and op != "N")
+    na = m if side == "L" else n
+    i = np.arange(na, dtype=np.float64)[:, None]
+    k = np.arange(na, dtype=np.float64)[None, :]
+    if side == "L":
+        r, th = (i + 1) / (k + .5), 2 * i - k
+    else:
+        r, th = (k + 1) / (i + .5), 2 * k - i
+    cx = np.dtype(dtype).kind == "c"
+    op_a = (r * np.exp(1j * th)).astype(dtype) if cx else r.astype(dtype)
+    skip = (i < k) if op_a_lower else (i > k)
+    if diag == "U":
+        skip = skip | (i == k)
+    op_a = np.where(skip, dt(-9.9), op_a)
+    ii = np.arange(m, dtype=np.float64)[:, None]
+    jj = np.arange(n, dtype=np.float64)[None, :]
+    if side == "L":
+        xr, xt = (ii + .5) / (jj + 2), ii + jj
+        kk = (ii + 1) if op_a_lower else (m - ii)
+        gr, gt = (ii + 1) / (jj + 2), 2 * ii + jj
+    else:
+        xr, xt = (jj + .5) / (ii + 2), ii + jj
+        kk = (n - jj) if op_a_lower else (jj + 1)
+        gr, gt = (jj + 1) / (ii + 2), ii + 2 * jj
+    kk = np.broadcast_to(kk, (m, n))
+    x = (xr * np.exp(1j * xt)).astype(dtype) if cx else np.broadcast_to(xr, (m, n)).astype(dtype)
+    gamma = (gr * np.exp(1j * gt)) if cx else np.broadcast_to(gr, (m, n))
+    b = (((kk - 1) * gamma + x) / alpha) if diag == "U" else (kk * gamma / alpha)
+    unop = {"N": lambda z: z, "T": lambda z: z.T, "C": lambda z: z.conj().T}
+    a = np.asfortranarray(unop[op](op_a).astype(dtype))
+    return a, np.asfortranarray(b.astype(dtype)), np.asfortranarray(np.broadcast_to(x, (m, n)).astype(dtype))
+
+
 def eps_of(dtype) -> float:
     return float(np.finfo(REAL_OF[type_char(dtype)]).eps)
 

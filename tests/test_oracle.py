@@ -289,6 +289,22 @@ def test_tile_trsm_closed_form(oracle, t):
             assert ok, (m, n, side, uplo, op, diag, md)
 
 
+@pytest.mark.parametrize("t", TYPES)
+def test_triangular_system_generator(oracle, t):
+    # oracle.triangular_system is the vectorised getTriangularSystem the solver tests use: it must agree with
+    # the element-by-element restatement above, i.e. the generic trsm maps its (A, B) onto its X
+    dt = oracle.DTYPES[t]
+    alpha = dt(complex(-1.2, .7)) if t in "cz" else dt(-1.2)
+    for (m, n) in [(3, 5), (17, 13), (13, 17)]:
+        for side, uplo, op, diag in itertools.product("LR", "LU", "NTC", "NU"):
+            a, b, x = oracle.triangular_system(side, uplo, op, diag, alpha, m, n, dt)
+            bb = b.copy(order="F")
+            oracle.trsm(side, uplo, op, diag, alpha, a, bb)
+            tol = 10 * (max(m, n) + 1) * err_of(oracle, t)
+            ok, md = oracle.check_near(x, bb, tol, tol)
+            assert ok, (m, n, side, uplo, op, diag, md)
+
+
 # ------------------------------------------------------------------ factorization
 @pytest.mark.parametrize("t", TYPES)
 @pytest.mark.parametrize("uplo", ["L", "U"])
