@@ -240,15 +240,16 @@ def local_nr_tiles(n, nb, grid, rank, src):
 
 
 def scatter(a: np.ndarray, nb: int, pr: int, pc: int, sr: int = 0, sc: int = 0, extra_ld: int = 0):
-    """Global n x n matrix -> dict {(r,c): local column-major array} (2-D block-cyclic,
+    """Global m x n matrix -> dict {(r,c): local column-major array} (2-D block-cyclic,
     ScaLAPACK local layout; misc/matrix_distribution.md).  Arrays have lld = max(1, rows)+extra_ld;
     the returned array is the (rows x cols) view."""
-    n = a.shape[0]
+    m, n = a.shape
+    mt = (m + nb - 1) // nb if m else 0
     nt = (n + nb - 1) // nb if n else 0
     out = {}
     for r in range(pr):
         for c in range(pc):
-            rows = local_size(n, nb, pr, r, sr)
+            rows = local_size(m, nb, pr, r, sr)
             cols = local_size(n, nb, pc, c, sc)
             store = np.full((max(1, rows) + extra_ld, max(cols, 1)), -77.0, dtype=a.dtype, order="F")
             loc = store[:rows, :cols]
@@ -256,7 +257,7 @@ def scatter(a: np.ndarray, nb: int, pr: int, pc: int, sr: int = 0, sc: int = 0, 
                 if rank_global_tile(gj, pc, sc) != c:
                     continue
                 lj = local_tile_from_global_tile(gj, pc, c, sc)
-                for gi in range(nt):
+                for gi in range(mt):
                     if rank_global_tile(gi, pr, sr) != r:
                         continue
                     li = local_tile_from_global_tile(gi, pr, r, sr)
@@ -266,17 +267,20 @@ def scatter(a: np.ndarray, nb: int, pr: int, pc: int, sr: int = 0, sc: int = 0, 
     return out
 
 
-def gather(locs, n: int, nb: int, pr: int, pc: int, sr: int = 0, sc: int = 0, dtype=None) -> np.ndarray:
+def gather(locs, n: int, nb: int, pr: int, pc: int, sr: int = 0, sc: int = 0, dtype=None, m=None) -> np.ndarray:
+    """Inverse of scatter; the global matrix is m x n (m defaults to n)."""
     dtype = dtype or next(iter(locs.values())).dtype
-    a = np.zeros((n, n), dtype=dtype, order="F")
+    m = n if m is None else m
+    a = np.zeros((m, n), dtype=dtype, order="F")
+    mt = (m + nb - 1) // nb if m else 0
     nt = (n + nb - 1) // nb if n else 0
     for gj in range(nt):
         c = rank_global_tile(gj, pc, sc)
         lj = local_tile_from_global_tile(gj, pc, c, sc)
-        for gi in range(nt):
+        for gi in range(mt):
             r = rank_global_tile(gi, pr, sr)
             li = local_tile_from_global_tile(gi, pr, r, sr)
-            rows = min(nb, n - gi * nb)
+            rows = min(nb, m - gi * nb)
             cols = min(nb, n - gj * nb)
             a[gi * nb:gi * nb + rows, gj * nb:gj * nb + cols] = \
                 locs[(r, c)][li * nb:li * nb + rows, lj * nb:lj * nb + cols]

@@ -42,13 +42,13 @@ def make_grid(dlaf, nprow, npcol, order):
     return g, rank_of
 
 
-def gather_global(loc, grid, n, nb, sr, sc, oracle):
-    """all ranks -> rank 0: the global matrix assembled from the local parts"""
+def gather_global(loc, grid, n, nb, sr, sc, oracle, m=None):
+    """all ranks -> rank 0: the global (m x) n matrix assembled from the local parts"""
     world = dist.get_world_size()
     parts = [None] * world
     dist.all_gather_object(parts, (grid.myrow, grid.mycol, np.ascontiguousarray(loc)))
     locs = {(r, c): np.asfortranarray(a) for r, c, a in parts}
-    return oracle.gather(locs, n, nb, grid.nprow, grid.npcol, sr, sc, dtype=loc.dtype)
+    return oracle.gather(locs, n, nb, grid.nprow, grid.npcol, sr, sc, dtype=loc.dtype, m=m)
 
 
 def main():
@@ -135,6 +135,28 @@ def main():
             ok &= bool(good)
             orig.close()
             fact.close()
+        # triangular solver: every side / uplo / op / diag on the reference's analytic systems
+        # (test/unit/solver/test_triangular.cpp:105-141), non-zero source ranks, both communication shapes
+        import itertools
+        for t, (m, n, nb) in [("d", (19, 25, 6)), ("z", (15, 7, 3)), ("d", (150, 70, 32)), ("s", (12, 13, 5)),
+                              ("d", (130, 200, 64))]:
+            dt = oracle.DTYPES[t]
+            alpha = dt(complex(-1.2, .7)) if t in "cz" else dt(-1.2)
+            for side, uplo, op, diag in itertools.product("LR", "LU", "NTC", "NU"):
+                a, b, x = oracle.triangular_system(side, uplo, op, diag, alpha, m, n, dt)
+                sr, sc = max(0, nprow - 1), min(1, npcol - 1)
+                la = np.asfortranarray(oracle.scatter(a, nb, nprow, npcol, sr, sc, extra_ld=1)[(grid.myrow, grid.mycol)])
+                lb = np.asfortranarray(oracle.scatter(b, nb, nprow, npcol, sr, sc, extra_ld=2)[(grid.myrow, grid.mycol)])
+                dlaf.triangular_solver(grid, side, uplo, op, diag, alpha, la, lb, nb, m=m, n=n, a_src=(sr, sc),
+                                       b_src=(sr, sc))
+                got = gather_global(lb, grid, n, nb, sr, sc, oracle, m=m)
+                if rank == 0:
+                    tol = 20 * (m + 1) * (8 if t in "cz" else 2) * oracle.eps_of(dt)   # test_triangular.cpp:139-140
+                    good, md = oracle.check_near(x, got, tol, tol)
+                    if not good:
+                        print(f"[dist_worker] solver FAILED {t} {side}{uplo}{op}{diag} {m}x{n} nb={nb} "
+                              f"grid {nprow}x{npcol}: max diff {md} tol {tol}", flush=True)
+                    ok &= bool(good)
         # analytic known-answer matrix through the ScaLAPACK-style entry (test_cholesky_c_api.cpp:108-155)
         n, nb = 34, 13
         a, l = oracle.cholesky_setters("L", n, np.float64)
