@@ -180,6 +180,13 @@ def triangular_solver(grid: Grid, side: str, uplo: str, op: str, diag: str, alph
         raise ValueError(f"dlaf_mi355x_triangular_solver_{t} failed with {r}")
 
 
+def solver_profile():
+    """(ms, flops) of the sweep of the last triangular solve on this process (device time, no staging)."""
+    ms, fl = C.c_double(0), C.c_double(0)
+    lib().dlaf_mi355x_solver_profile(C.byref(ms), C.byref(fl))
+    return ms.value, fl.value
+
+
 def pxtrsm(side: str, uplo: str, op: str, diag: str, m: int, n: int, alpha, a: np.ndarray, ia: int, ja: int, desca,
            b: np.ndarray, ib: int, jb: int, descb) -> None:
     """dlaf_mi355x_p{s,d,c,z}trsm: ScaLAPACK's p?trsm argument list (9-int descriptors)."""

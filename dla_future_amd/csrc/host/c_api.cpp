@@ -363,6 +363,11 @@ DLAF_MI355X_TRSM_ENTRY(c, std::complex<float>, dlaf_complex_c)
 DLAF_MI355X_TRSM_ENTRY(z, std::complex<double>, dlaf_complex_z)
 #undef DLAF_MI355X_TRSM_ENTRY
 
+int dlaf_mi355x_solver_profile(double* ms, double* flops) noexcept {
+  solver_last_profile(ms, flops);
+  return 0;
+}
+
 int dlaf_mi355x_matrix_create(int ctx, char type, char uplo, DLAF_descriptor d, dlaf_mi355x_matrix_t* out) noexcept {
   if (!out)
     return -1;

@@ -159,6 +159,8 @@ template <class T>
 int triangular_solver_host(Grid* g, char side, char uplo, char op, char diag, T alpha, const T* a, long lda, int a_isrc,
                            int a_jsrc, T* b, long ldb, long m, long n, int nb, int b_isrc, int b_jsrc);
 
+void solver_last_profile(double* ms, double* flops);
+
 void runtime_init();
 void runtime_finalize();
 bool runtime_initialized();

@@ -144,6 +144,10 @@ T conj_el(T v) {
   return v;
 }
 
+// device time of the last sweep on this process (HIP events on the compute stream; relayout and PCIe excluded)
+static double g_last_sweep_ms = 0;
+static double g_last_sweep_flops = 0;
+
 struct Events {
   std::vector<hipEvent_t> v;
   explicit Events(size_t n) : v(n) {
@@ -375,6 +379,11 @@ void solve_canonical(TileMatrix<T>& Td, TileMatrix<T>& Bd, bool upper, bool unit
     launch_update(ua, s_main, 0);
   };
 
+  hipEvent_t ev_t0, ev_t1;
+  DLAF_HIP_CHECK(hipEventCreate(&ev_t0));
+  DLAF_HIP_CHECK(hipEventCreate(&ev_t1));
+  DLAF_HIP_CHECK(hipEventRecord(ev_t0, s_main));
+
   // ---- the sweep --------------------------------------------------------------------------------------
   // s_main: TRSM(s) . U(s, next column) . TRSM(s+1) . U(s, the rest) . U(s+1, next column) ...  so that the
   // X panel of step s+1 is on the wire under the bulk of step s; T operands arrive one step ahead on s_comm
@@ -452,8 +461,18 @@ void solve_canonical(TileMatrix<T>& Td, TileMatrix<T>& Bd, bool upper, bool unit
   // the last step has nothing beyond it; its event only releases the buffers
   DLAF_HIP_CHECK(hipEventRecord(ev_free[(size_t) (nt - 1)], s_main));
 
+  DLAF_HIP_CHECK(hipEventRecord(ev_t1, s_main));
   DLAF_HIP_CHECK(hipStreamSynchronize(s_comm));
   DLAF_HIP_CHECK(hipStreamSynchronize(s_main));
+  {
+    float ms = 0;
+    DLAF_HIP_CHECK(hipEventElapsedTime(&ms, ev_t0, ev_t1));
+    g_last_sweep_ms = ms;
+    // whole-grid algorithmic flops: rows x n^2 (x4 complex)
+    g_last_sweep_flops = (TypeInfo<T>::is_complex ? 4.0 : 1.0) * (double) Bd.rows.n * (double) Bd.cols.n * (double) Bd.cols.n;
+  }
+  (void) hipEventDestroy(ev_t0);
+  (void) hipEventDestroy(ev_t1);
   (void) hipEventDestroy(ev_prep);
   (void) hipStreamDestroy(s_main);
   (void) hipStreamDestroy(s_comm);
@@ -471,6 +490,13 @@ void solve_canonical(TileMatrix<T>& Td, TileMatrix<T>& Bd, bool upper, bool unit
 }
 
 }  // namespace
+
+void solver_last_profile(double* ms, double* flops) {
+  if (ms)
+    *ms = g_last_sweep_ms;
+  if (flops)
+    *flops = g_last_sweep_flops;
+}
 
 // Host entry: a (local part of the triangular matrix, column-major lda), b (local part of the m x n right-hand
 // sides, ldb) on the grid; b is overwritten by the solution.

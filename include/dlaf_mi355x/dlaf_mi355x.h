@@ -122,6 +122,11 @@ DLAF_EXTERN_C void dlaf_mi355x_pztrsm(char side, char uplo, char op, char diag, 
                                       const int desca[9], dlaf_complex_z* b, int ib, int jb,
                                       const int descb[9]) DLAF_NOEXCEPT;
 
+/* Device time (ms, HIP events on the compute stream) of the sweep of the last triangular solve on this process
+ * -- relayout and PCIe staging excluded -- and the whole-grid algorithmic flops it stands for (m n^2 for side
+ * R, m^2 n for side L; x4 complex). */
+DLAF_EXTERN_C int dlaf_mi355x_solver_profile(double* ms, double* flops) DLAF_NOEXCEPT;
+
 /* ---- synthetic input ------------------------------------------------------------------------ */
 /* Fills this process's local array (column-major, ld) of the n x n matrix with the reference's
  * random Hermitian positive definite matrix: per global tile a std::mt19937_64 seeded with the
