@@ -18,6 +18,7 @@
 #include <dlaf_c/factorization/cholesky.h>
 #include <dlaf_c/grid.h>
 #include <dlaf_c/init.h>
+#include <dlaf_mi355x/dlaf_mi355x.h>
 
 static int numroc(int n, int nb, int iproc, int isrc, int nprocs) {
   /* ScaLAPACK NUMROC */
@@ -76,6 +77,54 @@ static int run(int ctx, int nprow, int npcol, int myrow, int mycol, char uplo, i
   else
     dlaf_pdpotrf(uplo, n, ad, 1, 1, desca, &info);
   int bad = info != 0;
+  /* the next row of the path (p?trsm, dlaf_mi355x.h): with the factor, solve A X = A for X = I */
+  if (!bad && n > 0) {
+    double complex* bz = cx ? malloc(sizeof(double complex) * elems) : NULL;
+    double* bd = cx ? NULL : malloc(sizeof(double) * elems);
+    for (int jl = 0; jl < nloc; ++jl) {
+      int gj = ((jl / nb) * npcol + (npcol + mycol - jsrc) % npcol) * nb + jl % nb;
+      for (int il = 0; il < mloc; ++il) {
+        int gi = ((il / nb) * nprow + (nprow + myrow - isrc) % nprow) * nb + il % nb;
+        /* full Hermitian A from its stored triangle */
+        int in_tri = (uplo == 'L') ? gi >= gj : gi <= gj;
+        double complex v = in_tri ? el_a(uplo, gi, gj, cx) : conj(el_a(uplo, gj, gi, cx));
+        if (cx)
+          bz[il + (size_t) jl * lld] = v;
+        else
+          bd[il + (size_t) jl * lld] = creal(v);
+      }
+    }
+    const double one_d = 1.0;
+    const double complex one_z = 1.0;
+    /* uplo L: L Y = B, L^H X = Y;   uplo U: U^H Y = B, U X = Y */
+    const char op1 = uplo == 'L' ? 'N' : 'C', op2 = uplo == 'L' ? 'C' : 'N';
+    if (cx) {
+      dlaf_mi355x_pztrsm('L', uplo, op1, 'N', n, n, (const dlaf_complex_z*) &one_z, (const dlaf_complex_z*) az, 1, 1,
+                         desca, (dlaf_complex_z*) bz, 1, 1, desca);
+      dlaf_mi355x_pztrsm('L', uplo, op2, 'N', n, n, (const dlaf_complex_z*) &one_z, (const dlaf_complex_z*) az, 1, 1,
+                         desca, (dlaf_complex_z*) bz, 1, 1, desca);
+    }
+    else {
+      dlaf_mi355x_pdtrsm('L', uplo, op1, 'N', n, n, &one_d, ad, 1, 1, desca, bd, 1, 1, desca);
+      dlaf_mi355x_pdtrsm('L', uplo, op2, 'N', n, n, &one_d, ad, 1, 1, desca, bd, 1, 1, desca);
+    }
+    const double stol = 100.0 * (n + 1) * (cx ? 8 : 2) * DBL_EPSILON;
+    for (int jl = 0; jl < nloc && !bad; ++jl) {
+      int gj = ((jl / nb) * npcol + (npcol + mycol - jsrc) % npcol) * nb + jl % nb;
+      for (int il = 0; il < mloc; ++il) {
+        int gi = ((il / nb) * nprow + (nprow + myrow - isrc) % nprow) * nb + il % nb;
+        double complex g = cx ? bz[il + (size_t) jl * lld] : bd[il + (size_t) jl * lld];
+        if (cabs(g - (gi == gj ? 1.0 : 0.0)) > stol) {
+          fprintf(stderr, "rank (%d,%d) %c%c n=%d nb=%d: solve (%d,%d) got %g%+gi\n", myrow, mycol, cx ? 'z' : 'd',
+                  uplo, n, nb, gi, gj, creal(g), cimag(g));
+          bad = 1;
+          break;
+        }
+      }
+    }
+    free(bz);
+    free(bd);
+  }
   const double tol = 4.0 * (n + 1) * (cx ? 8 : 2) * DBL_EPSILON;
   for (int jl = 0; jl < nloc && !bad; ++jl) {
     int gj = ((jl / nb) * npcol + (npcol + mycol - jsrc) % npcol) * nb + jl % nb;
