@@ -44,7 +44,8 @@ struct UpdateArgs {
   int rect = 0;
   int nt_c = 0, last_cols = 0;
 };
-// role: 0 trailing bulk, 1 lookahead column, 2 in-tile POTRF update (same code, separate kernel names)
+// role: 0 trailing bulk, 1 lookahead column, 2 in-tile POTRF update / single-tile entries, 3 residual checker
+// and triangular solver (same code, separate kernel names, so that profiles of the factorization stay clean)
 // max_blocks > 0 (with counters = 8 device words of scratch): launch at most that many workgroups and
 // let them pull work items (persistent form): what is left of the GPU stays free for kernels that
 // must run beside the update.

@@ -232,7 +232,8 @@ __device__ __forceinline__ void update_block(const UpdateArgs<T>& p, const Updat
   }
 }
 
-// ROLE only names the instantiation (0 trailing bulk, 1 lookahead column, 2 in-tile POTRF update) so
+// ROLE only names the instantiation (0 trailing bulk, 1 lookahead column, 2 in-tile POTRF / single-tile
+// entries, 3 callers outside the factorization: residual checker, triangular solver) so
 // that rocprof statistics and the library's own HIP-event timing refer to the same set of launches.
 // Work item v -> block w: the 8 XCDs (workgroup id mod 8 under round-robin dispatch) get contiguous runs
 // of 8x8-block patches.  Persistent form: gridDim.x workgroups stride over the work items, which (a)
@@ -343,6 +344,7 @@ void launch_update(const UpdateArgs<T>& a, hipStream_t stream, int role, long ma
     switch (role) {
       case 0: go(vtag, std::integral_constant<int, 0>{}); break;
       case 1: go(vtag, std::integral_constant<int, 1>{}); break;
+      case 3: go(vtag, std::integral_constant<int, 3>{}); break;
       default: go(vtag, std::integral_constant<int, 2>{}); break;
     }
   };
@@ -372,9 +374,11 @@ static void update_init_one() {
   SET_ONE(true, 0);
   SET_ONE(true, 1);
   SET_ONE(true, 2);
+  SET_ONE(true, 3);
   SET_ONE(false, 0);
   SET_ONE(false, 1);
   SET_ONE(false, 2);
+  SET_ONE(false, 3);
 #undef SET_ONE
 }
 

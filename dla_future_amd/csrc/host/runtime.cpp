@@ -210,13 +210,13 @@ void DeviceMatrix<T>::create(Grid* g, char uplo_, long n_, int nb_, int isrc, in
   DLAF_HIP_CHECK(hipStreamCreateWithPriority(&s_comm, hipStreamNonBlocking, hi));
   const size_t ne = (size_t) (nt > 0 ? nt : 1);
   ev_panel = make_events(ne);
-  ev_low = make_events(ne);
+  ev_done = make_events(1);
   ev_high = make_events(ne);
   ev_diag = make_events(ne);
   ev_bcast = make_events(ne);
   ev_head = make_events(ne);
   ev_headb = make_events(ne);
-  ev_bcastT = make_events(2);
+  ev_start = make_events(2);
 }
 
 template <class T>
@@ -224,7 +224,7 @@ void DeviceMatrix<T>::destroy() {
   if (!tiles)
     return;
   (void) hipDeviceSynchronize();
-  for (auto* v : {&ev_panel, &ev_low, &ev_high, &ev_diag, &ev_bcast, &ev_bcastT, &ev_head, &ev_headb}) {
+  for (auto* v : {&ev_panel, &ev_done, &ev_high, &ev_diag, &ev_bcast, &ev_start, &ev_head, &ev_headb}) {
     for (auto e : *v)
       (void) hipEventDestroy(e);
     v->clear();
@@ -482,9 +482,9 @@ void DeviceMatrix<T>::factorize_async() {
     ps.launches = 0;
   }
   DLAF_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int), s_panel));
-  DLAF_HIP_CHECK(hipEventRecord(ev_bcastT[0], s_panel));
-  DLAF_HIP_CHECK(hipStreamWaitEvent(s_main, ev_bcastT[0], 0));
-  DLAF_HIP_CHECK(hipStreamWaitEvent(s_comm, ev_bcastT[0], 0));
+  DLAF_HIP_CHECK(hipEventRecord(ev_start[0], s_panel));
+  DLAF_HIP_CHECK(hipStreamWaitEvent(s_main, ev_start[0], 0));
+  DLAF_HIP_CHECK(hipStreamWaitEvent(s_comm, ev_start[0], 0));
 
   // algorithmic work of one grouped update launch (BASELINE.md roofline table):
   // gemm tile 2 m n k flop / (m k + n k + 2 m n) elements, herk tile n (n+1) k flop / (n k + n^2) elements
@@ -845,8 +845,8 @@ void DeviceMatrix<T>::factorize_async() {
       prev = cur;
     }
   }
-  DLAF_HIP_CHECK(hipEventRecord(ev_low[0], s_main));
-  DLAF_HIP_CHECK(hipStreamWaitEvent(s_panel, ev_low[0], 0));
+  DLAF_HIP_CHECK(hipEventRecord(ev_done[0], s_main));
+  DLAF_HIP_CHECK(hipStreamWaitEvent(s_panel, ev_done[0], 0));
   DLAF_HIP_CHECK(hipMemcpyAsync(info_host, info, sizeof(int), hipMemcpyDeviceToHost, s_panel));
 }
 
@@ -1002,7 +1002,7 @@ void DeviceMatrix<T>::residual_of(DeviceMatrix<T>& L, double* max_diff, double* 
     ua.nt = (int) nt;
     ua.last_rows = rows.last_extent();
     ua.info = info;
-    launch_update(ua, s, 0);
+    launch_update(ua, s, 3);
     if (dist)
       DLAF_HIP_CHECK(hipStreamSynchronize(s));  // the single panel workspace is reused by the next step
   }
@@ -1179,7 +1179,7 @@ void tile_herk(char uplo, int n, int k, const T* a, int lda, T* c, int ldc) {
   ua.nt = 1;
   ua.last_rows = n;
   ua.info = info.p;
-  launch_update(ua, s);
+  launch_update(ua, s, 2);
   launch_copy2d(tmpc.p, (long) n, dc.p, (long) n, n, n, tr ? 1 : 0, tr ? 2 : 1, s);
   DLAF_HIP_CHECK(hipMemcpy2DAsync(c, (size_t) ldc * sizeof(T), tmpc.p, (size_t) n * sizeof(T), (size_t) n * sizeof(T),
                                   (size_t) n, hipMemcpyDeviceToHost, s));
@@ -1247,7 +1247,7 @@ void tile_gemm(char uplo, int m, int n, int k, const T* a, int lda, const T* b, 
   ua.last_rows = sq;
   ua.info = info.p;
   // c_tsr = 0: tile row index does not move the base
-  launch_update(ua, s);
+  launch_update(ua, s, 2);
   launch_copy2d(tmpc.p, (long) m, pC.p, (long) sq, m, n, tr ? 1 : 0, 0, s);
   DLAF_HIP_CHECK(hipMemcpy2DAsync(c, (size_t) ldc * sizeof(T), tmpc.p, (size_t) m * sizeof(T), (size_t) m * sizeof(T),
                                   (size_t) n, hipMemcpyDeviceToHost, s));

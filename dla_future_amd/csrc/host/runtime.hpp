@@ -103,7 +103,9 @@ struct DeviceMatrix : MatrixBase {
   int* info_host = nullptr; // pinned
 
   hipStream_t s_high = nullptr, s_low = nullptr, s_comm = nullptr;
-  std::vector<hipEvent_t> ev_panel, ev_low, ev_high, ev_diag, ev_bcast, ev_bcastT, ev_head, ev_headb;
+  // per step: panel solved, lookahead columns updated, diagonal tile ready, panels received, head tile
+  // solved / received; ev_start / ev_done fence a factorization on the three streams
+  std::vector<hipEvent_t> ev_panel, ev_high, ev_diag, ev_bcast, ev_head, ev_headb, ev_start, ev_done;
 
   // live timing of the launch classes with HIP events on the stream each class runs on
   // (kind 0: trailing bulk update, 1: lookahead-column update, 2: panel TRSM, 3: tile POTRF chain)

@@ -376,7 +376,7 @@ void solve_canonical(TileMatrix<T>& Td, TileMatrix<T>& Bd, bool upper, bool unit
     ua.nt_c = (int) nt;
     ua.last_cols = Bd.cols.last_extent();
     ua.info = info;
-    launch_update(ua, s_main, 0);
+    launch_update(ua, s_main, 3);
   };
 
   hipEvent_t ev_t0, ev_t1;
