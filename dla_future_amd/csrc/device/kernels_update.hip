@@ -150,25 +150,44 @@ __device__ __forceinline__ void update_block(const UpdateArgs<T>& p, const Updat
     typedef R r2 __attribute__((ext_vector_type(2)));
     const bool wide = !masked && VEC && ((p.ldc * (long) sizeof(T)) % 16 == 0) &&
                       (reinterpret_cast<uintptr_t>(C) % 16 == 0);
+#ifndef DLAF_EPI_COLS
+#define DLAF_EPI_COLS 1
+#endif
+    if (wide) {
+      // DLAF_EPI_COLS accumulator columns (a column = one (j, v) pair, TM/2 16-byte accesses per lane) are
+      // loaded together before any is subtracted and stored
+      constexpr int NB = DLAF_EPI_COLS;
 #pragma unroll
-    for (int j = 0; j < Cfg::TN; ++j) {
+      for (int i0 = 0; i0 < Cfg::TN * 4; i0 += NB) {
+        r2 cv[NB][Cfg::TM / 2];
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int nl = wn * Cfg::WN + acc_n<Cfg>(j, g, v);
-        T* col = C + (long) nl * p.ldc;
-        if (wide) {
-          r2 cv[Cfg::TM / 2];
+        for (int ii = 0; ii < NB; ++ii) {
+          const int j = (i0 + ii) / 4, v = (i0 + ii) % 4;
+          const T* col = C + (long) (wn * Cfg::WN + acc_n<Cfg>(j, g, v)) * p.ldc;
 #pragma unroll
           for (int q = 0; q < Cfg::TM / 2; ++q)
-            cv[q] = *reinterpret_cast<const r2*>(col + wm * Cfg::WM + q * 32 + 2 * c);
+            cv[ii][q] = *reinterpret_cast<const r2*>(col + wm * Cfg::WM + q * 32 + 2 * c);
+        }
+#pragma unroll
+        for (int ii = 0; ii < NB; ++ii) {
+          const int j = (i0 + ii) / 4, v = (i0 + ii) % 4;
+          T* col = C + (long) (wn * Cfg::WN + acc_n<Cfg>(j, g, v)) * p.ldc;
 #pragma unroll
           for (int q = 0; q < Cfg::TM / 2; ++q) {
-            cv[q][0] -= acc.re[2 * q][j][v];
-            cv[q][1] -= acc.re[2 * q + 1][j][v];
-            *reinterpret_cast<r2*>(col + wm * Cfg::WM + q * 32 + 2 * c) = cv[q];
+            cv[ii][q][0] -= acc.re[2 * q][j][v];
+            cv[ii][q][1] -= acc.re[2 * q + 1][j][v];
+            *reinterpret_cast<r2*>(col + wm * Cfg::WM + q * 32 + 2 * c) = cv[ii][q];
           }
         }
-        else {
+      }
+    }
+    else {
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int nl = wn * Cfg::WN + acc_n<Cfg>(j, g, v);
+          T* col = C + (long) nl * p.ldc;
 #pragma unroll
           for (int i = 0; i < Cfg::TM; ++i) {
             const int ml = wm * Cfg::WM + acc_m<Cfg>(i, c);
