@@ -16,11 +16,11 @@ and a GPU and fails loudly otherwise.
 """
 from .capi import (DLAFDescriptor, LibraryNotBuilt, lib, lib_path, type_char, version)  # noqa: F401
 from .cholesky import (DeviceMatrix, Grid, cholesky_factorization, finalize, initialize, make_descriptor,  # noqa: F401
-                       pxpotrf, pxtrsm, set_random_hermitian_positive_definite, tile_gemm, tile_herk, tile_potrf,
+                       pxpotrf, pxpotrs, pxtrsm, set_random_hermitian_positive_definite, tile_gemm, tile_herk, tile_potrf,
                        tile_trsm, triangular_solver, solver_profile)
 from . import distribution  # noqa: F401
 
 __all__ = ["DLAFDescriptor", "DeviceMatrix", "Grid", "LibraryNotBuilt", "cholesky_factorization", "distribution",
-           "finalize", "initialize", "lib", "lib_path", "make_descriptor", "pxpotrf", "pxtrsm",
+           "finalize", "initialize", "lib", "lib_path", "make_descriptor", "pxpotrf", "pxpotrs", "pxtrsm",
            "set_random_hermitian_positive_definite", "solver_profile", "tile_gemm", "tile_herk", "tile_potrf", "tile_trsm",
            "triangular_solver", "type_char", "version"]

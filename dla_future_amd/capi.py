@@ -86,6 +86,10 @@ SIGNATURES = {
     "dlaf_mi355x_pdtrsm": (None, [_ch, _ch, _ch, _ch, _i, _i, _vp, _vp, _i, _i, _IP, _vp, _i, _i, _IP]),
     "dlaf_mi355x_pctrsm": (None, [_ch, _ch, _ch, _ch, _i, _i, _vp, _vp, _i, _i, _IP, _vp, _i, _i, _IP]),
     "dlaf_mi355x_pztrsm": (None, [_ch, _ch, _ch, _ch, _i, _i, _vp, _vp, _i, _i, _IP, _vp, _i, _i, _IP]),
+    "dlaf_mi355x_pspotrs": (None, [_ch, _i, _i, _vp, _i, _i, _IP, _vp, _i, _i, _IP, _IP]),
+    "dlaf_mi355x_pdpotrs": (None, [_ch, _i, _i, _vp, _i, _i, _IP, _vp, _i, _i, _IP, _IP]),
+    "dlaf_mi355x_pcpotrs": (None, [_ch, _i, _i, _vp, _i, _i, _IP, _vp, _i, _i, _IP, _IP]),
+    "dlaf_mi355x_pzpotrs": (None, [_ch, _i, _i, _vp, _i, _i, _IP, _vp, _i, _i, _IP, _IP]),
     "dlaf_mi355x_solver_profile": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dlaf_mi355x_set_random_hpd": (_i, [_i, _ch, _vp, DLAFDescriptor, _i]),
     "dlaf_mi355x_tile_potrf": (_i, [_ch, _ch, _i, _vp, _i]),

@@ -180,6 +180,18 @@ def triangular_solver(grid: Grid, side: str, uplo: str, op: str, diag: str, alph
         raise ValueError(f"dlaf_mi355x_triangular_solver_{t} failed with {r}")
 
 
+def pxpotrs(uplo: str, n: int, nrhs: int, a: np.ndarray, ia: int, ja: int, desca, b: np.ndarray, ib: int, jb: int,
+            descb) -> int:
+    """dlaf_mi355x_p{s,d,c,z}potrs: A X = B with the factor p?potrf left in `a`; returns info."""
+    t = type_char(b.dtype)
+    da = (C.c_int * 9)(*[int(x) for x in desca])
+    db = (C.c_int * 9)(*[int(x) for x in descb])
+    info = C.c_int(-999)
+    getattr(lib(), f"dlaf_mi355x_p{t}potrs")(uplo.encode(), n, nrhs, _ptr(a), ia, ja, da, _ptr(b), ib, jb, db,
+                                             C.byref(info))
+    return info.value
+
+
 def solver_profile():
     """(ms, flops) of the sweep of the last triangular solve on this process (device time, no staging)."""
     ms, fl = C.c_double(0), C.c_double(0)

@@ -177,6 +177,18 @@ void pxtrsm(char side, char uplo, char op, char diag, int m, int n, const HT* al
   (void) triangular_solver_c<HT>(desca[1], side, uplo, op, diag, alpha, a, da, b, db);
 }
 
+// ScaLAPACK p?potrs: solve A X = B with the factor p?potrf left in a (uplo L: L L^H, uplo U: U^H U)
+template <class HT>
+void pxpotrs(char uplo, int n, int nrhs, const HT* a, int ia, int ja, const int desca[9], HT* b, int ib, int jb,
+             const int descb[9], int* info) {
+  const HT one(1);
+  const bool lower = (uplo == 'L' || uplo == 'l');
+  pxtrsm<HT>('L', uplo, lower ? 'N' : 'C', 'N', n, nrhs, &one, a, ia, ja, desca, b, ib, jb, descb);
+  pxtrsm<HT>('L', uplo, lower ? 'C' : 'N', 'N', n, nrhs, &one, a, ia, ja, desca, b, ib, jb, descb);
+  if (info)
+    *info = 0;
+}
+
 struct MatrixHandle {
   std::unique_ptr<MatrixBase> m;
   char type;
@@ -357,6 +369,17 @@ int dlaf_mi355x_grid_host_bcast(int ctx, int axis, int root, void* host_buf, siz
     pxtrsm<HT>(side, uplo, op, diag, m, n, reinterpret_cast<const HT*>(alpha), reinterpret_cast<const HT*>(a), ia, \
                ja, desca, reinterpret_cast<HT*>(b), ib, jb, descb);                                              \
   }
+#define DLAF_MI355X_POTRS_ENTRY(S, HT, CT)                                                                       \
+  void dlaf_mi355x_p##S##potrs(char uplo, int n, int nrhs, const CT* a, int ia, int ja, const int desca[9], CT* b,  \
+                               int ib, int jb, const int descb[9], int* info) noexcept {                        \
+    pxpotrs<HT>(uplo, n, nrhs, reinterpret_cast<const HT*>(a), ia, ja, desca, reinterpret_cast<HT*>(b), ib, jb,  \
+                descb, info);                                                                                   \
+  }
+DLAF_MI355X_POTRS_ENTRY(s, float, float)
+DLAF_MI355X_POTRS_ENTRY(d, double, double)
+DLAF_MI355X_POTRS_ENTRY(c, std::complex<float>, dlaf_complex_c)
+DLAF_MI355X_POTRS_ENTRY(z, std::complex<double>, dlaf_complex_z)
+#undef DLAF_MI355X_POTRS_ENTRY
 DLAF_MI355X_TRSM_ENTRY(s, float, float)
 DLAF_MI355X_TRSM_ENTRY(d, double, double)
 DLAF_MI355X_TRSM_ENTRY(c, std::complex<float>, dlaf_complex_c)

@@ -122,6 +122,18 @@ DLAF_EXTERN_C void dlaf_mi355x_pztrsm(char side, char uplo, char op, char diag, 
                                       const int desca[9], dlaf_complex_z* b, int ib, int jb,
                                       const int descb[9]) DLAF_NOEXCEPT;
 
+/* ScaLAPACK p?potrs: A X = B with the factor dlaf_p?potrf left in a (two triangular solves; b is overwritten) */
+DLAF_EXTERN_C void dlaf_mi355x_pspotrs(char uplo, int n, int nrhs, const float* a, int ia, int ja, const int desca[9],
+                                       float* b, int ib, int jb, const int descb[9], int* info) DLAF_NOEXCEPT;
+DLAF_EXTERN_C void dlaf_mi355x_pdpotrs(char uplo, int n, int nrhs, const double* a, int ia, int ja, const int desca[9],
+                                       double* b, int ib, int jb, const int descb[9], int* info) DLAF_NOEXCEPT;
+DLAF_EXTERN_C void dlaf_mi355x_pcpotrs(char uplo, int n, int nrhs, const dlaf_complex_c* a, int ia, int ja,
+                                       const int desca[9], dlaf_complex_c* b, int ib, int jb, const int descb[9],
+                                       int* info) DLAF_NOEXCEPT;
+DLAF_EXTERN_C void dlaf_mi355x_pzpotrs(char uplo, int n, int nrhs, const dlaf_complex_z* a, int ia, int ja,
+                                       const int desca[9], dlaf_complex_z* b, int ib, int jb, const int descb[9],
+                                       int* info) DLAF_NOEXCEPT;
+
 /* Device time (ms, HIP events on the compute stream) of the sweep of the last triangular solve on this process
  * -- relayout and PCIe staging excluded -- and the whole-grid algorithmic flops it stands for (m n^2 for side
  * R, m^2 n for side L; x4 complex). */

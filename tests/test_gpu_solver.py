@@ -90,3 +90,11 @@ def test_pdtrsm_after_pdpotrf_solves_the_system(dlaf, grid, oracle):
     dlaf.pxtrsm("L", "L", "N", "N", n, nrhs, 1.0, fact, 1, 1, desca, rhs, 1, 1, descb)
     dlaf.pxtrsm("L", "L", "C", "N", n, nrhs, 1.0, fact, 1, 1, desca, rhs, 1, 1, descb)
     assert np.abs(rhs - xs).max() <= 100 * n * oracle.eps_of(np.float64)
+    # the same through p?potrs, upper factor, complex
+    a0 = oracle.set_random_hpd(n, nb, np.complex128)
+    xs = np.asfortranarray(rng.uniform(-1, 1, (n, nrhs)) + 1j * rng.uniform(-1, 1, (n, nrhs)))
+    rhs = np.asfortranarray(a0 @ xs)
+    fact = a0.copy(order="F")
+    assert dlaf.pxpotrf("U", n, fact, 1, 1, desca) == 0
+    assert dlaf.pxpotrs("U", n, nrhs, fact, 1, 1, desca, rhs, 1, 1, descb) == 0
+    assert np.abs(rhs - xs).max() <= 100 * n * oracle.eps_of(np.float64)
