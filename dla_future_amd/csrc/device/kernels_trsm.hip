@@ -22,6 +22,10 @@ struct TrsmCfg {
   using type = BlockCfg<T, 128, kDiagBlock, 32, kDiagBlock, 16>;
   static constexpr int min_waves = 2;
 };
+// (A paired-row, direct-to-LDS, 3-stage configuration -- BlockCfg<double, 128, 64, 32, 64, 16, true, 3> -- is
+// supported by this kernel and was measured: no gain.  A strip is a chain of 16 dependent block steps run by
+// four waves; its floor is the MFMA time of that chain plus ~7 us per step of exposed B_j / inv(L_jj) loads,
+// not the K loop's global latency.)
 template <>
 struct TrsmCfg<cdouble> {
   using type = BlockCfg<cdouble, 128, kDiagBlock, 32, kDiagBlock, 8>;
@@ -88,10 +92,10 @@ __global__ __launch_bounds__(kThreads, TrsmCfg<T>::min_waves) void trsm_kernel(T
     for (int j2 = 0; j2 < Cfg::TN; ++j2)
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        const int nl = j2 * 16 + Mma<R>::irow(g, v);
+        const int nl = acc_n<Cfg>(j2, g, v);
 #pragma unroll
         for (int i = 0; i < Cfg::TM; ++i) {
-          const int ml = wm * Cfg::WM + i * 16 + c;
+          const int ml = wm * Cfg::WM + acc_m<Cfg>(i, c);
           T bv = zero_el<T>();
           if (full || (ml < mrows && nl < jb))
             bv = Bj[ml + (long) nl * p.ldb];
@@ -126,14 +130,22 @@ __global__ __launch_bounds__(kThreads, TrsmCfg<T>::min_waves) void trsm_kernel(T
       }
 #pragma unroll
       for (int ct = 0; ct < Cfg::TN; ++ct) {
-        // W lower triangular: W[n2][k] = 0 for k > n2;  upper: = 0 for k < n2
-        if (UPPER ? (ct < j2) : (ct > j2))
-          continue;
+        // W lower triangular: W[n2][k] = 0 for k > n2;  upper: = 0 for k < n2.  X tile j2 holds the natural
+        // columns 16 j2 .. 16 j2 + 15; with the paired-row map Y tile ct holds columns of the 32-wide group
+        // ct / 2, so whole groups are skipped (the zeros inside a group are multiplied)
+        if constexpr (Cfg::PAIRED) {
+          if (UPPER ? ((ct >> 1) < (j2 >> 1)) : ((ct >> 1) > (j2 >> 1)))
+            continue;
+        }
+        else {
+          if (UPPER ? (ct < j2) : (ct > j2))
+            continue;
+        }
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           // accumulator register v of lane-group g holds k = 16*ct + irow(g, v): read the partner
           // fragment of W at exactly that k ("accumulator as next operand")
-          const int kabs = 16 * ct + Mma<R>::irow(g, v);
+          const int kabs = acc_n<Cfg>(ct, g, v);
           const R w_re = Ws[kabs * LDW + j2 * 16 + c];
           R w_im = R(0);
           if constexpr (Cfg::CX)
@@ -155,7 +167,7 @@ __global__ __launch_bounds__(kThreads, TrsmCfg<T>::min_waves) void trsm_kernel(T
         const int nl = j2 * 16 + Mma<R>::irow(g, v);
 #pragma unroll
         for (int i = 0; i < Cfg::TM; ++i) {
-          const int ml = wm * Cfg::WM + i * 16 + c;
+          const int ml = wm * Cfg::WM + acc_m<Cfg>(i, c);
           if (full || (ml < mrows && nl < jb)) {
             if constexpr (Cfg::CX)
               Bj[ml + (long) nl * p.ldb] = T{xre[i][v], xim[i][v]};

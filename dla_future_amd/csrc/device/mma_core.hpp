@@ -31,9 +31,14 @@ struct BlockCfg {
   static_assert(!PAIRED || (TM % 2 == 0 && TN % 2 == 0), "paired rows: even tile counts");
   static constexpr int PAD = PAIRED_ ? 0 : kLdsPad;
   static constexpr int LDA = BM + PAD, LDB = BN + PAD;
-  // direct-to-LDS staging: one wave instruction (64 lanes x 16 B) must be exactly one slab column
-  static constexpr bool GLDS = (PAIRED && sizeof(T) * BM == 1024 && sizeof(T) * BN == 1024 && (BK % 4 == 0)) ||
-                               (CXI && sizeof(T) == 16 && BM % 64 == 0 && BN % 64 == 0);
+  // direct-to-LDS staging: one wave instruction (64 lanes x 16 B = 1 KiB, contiguous in LDS) moves CPI whole
+  // slab columns of the unpadded image (1 for 128 fp64 rows, 2 for 64 fp64 rows, ...); every wave issues the
+  // same number of them per slab
+  static constexpr int CPI_A = CX ? 1 : 1024 / ((int) sizeof(T) * BM), CPI_B = CX ? 1 : 1024 / ((int) sizeof(T) * BN);
+  static constexpr bool GLDS =
+      (PAIRED && CPI_A >= 1 && CPI_B >= 1 && CPI_A * (int) sizeof(T) * BM == 1024 &&
+       CPI_B * (int) sizeof(T) * BN == 1024 && BK % (4 * CPI_A) == 0 && BK % (4 * CPI_B) == 0) ||
+      (CXI && sizeof(T) == 16 && BM % 64 == 0 && BN % 64 == 0);
   static constexpr int A_PLANE = BK * LDA, B_PLANE = BK * LDB;
   static constexpr int A_ELEMS = (CX ? 2 : 1) * A_PLANE, B_ELEMS = (CX ? 2 : 1) * B_PLANE;
   static constexpr int BUF_ELEMS = A_ELEMS + B_ELEMS;
@@ -179,13 +184,20 @@ __device__ __forceinline__ void stage_glds(const T* __restrict__ A, long lda, co
     return;
   }
   constexpr int PER = 16 / (int) sizeof(T);  // elements per lane
+  // one instruction = CPI consecutive columns: lane -> (column lane / LPC, rows (lane % LPC) * PER ...)
+  constexpr int LPC_A = 64 / Cfg::CPI_A, LPC_B = 64 / Cfg::CPI_B;
+  constexpr int NA = Cfg::BK / Cfg::CPI_A / 4, NB = Cfg::BK / Cfg::CPI_B / 4;  // instructions per wave
 #pragma unroll
-  for (int q = 0; q < Cfg::BK / 4; ++q) {
-    const int k = wave * (Cfg::BK / 4) + q;
-    const T* ga = A + lane * PER + (long) (k0 + k) * lda;
-    const T* gb = B + lane * PER + (long) (k0 + k) * ldb;
+  for (int q = 0; q < NA; ++q) {
+    const int k = (wave * NA + q) * Cfg::CPI_A;
+    const T* ga = A + (lane % LPC_A) * PER + (long) (k0 + k + lane / LPC_A) * lda;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) ga,
                                      (__attribute__((address_space(3))) void*) (buf + k * Cfg::LDA), 16, 0, 0);
+  }
+#pragma unroll
+  for (int q = 0; q < NB; ++q) {
+    const int k = (wave * NB + q) * Cfg::CPI_B;
+    const T* gb = B + (lane % LPC_B) * PER + (long) (k0 + k + lane / LPC_B) * ldb;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) gb,
                                      (__attribute__((address_space(3))) void*) (buf + Cfg::A_ELEMS + k * Cfg::LDB), 16,
                                      0, 0);
@@ -211,7 +223,8 @@ __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda,
     // consumed.  Each wave issues LPS loads per slab; "vmcnt(LPS*(STAGES-2))" therefore means "my share
     // of slab kt+1 has landed", and the raw barrier extends that to every wave's share.
     constexpr int ST = Cfg::STAGES;
-    constexpr int LPS = Cfg::CXI ? (Cfg::BK * (Cfg::BM / 64) + Cfg::BK * (Cfg::BN / 64)) / 4 : 2 * (Cfg::BK / 4);
+    constexpr int LPS = Cfg::CXI ? (Cfg::BK * (Cfg::BM / 64) + Cfg::BK * (Cfg::BN / 64)) / 4
+                                 : Cfg::BK / Cfg::CPI_A / 4 + Cfg::BK / Cfg::CPI_B / 4;
 #pragma unroll
     for (int s = 0; s < ST - 1; ++s)
       if (s < nk)
