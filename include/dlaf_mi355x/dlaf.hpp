@@ -1,0 +1,384 @@
+/* dlaf.hpp -- header-only C++ facade over the C ABI of libdlaf_mi355x.so with the names of the reference's
+ * C++ interface for the Cholesky path, so that code written against DLA-Future reads the same:
+ *
+ *     dlaf::Matrix<T, Device::CPU> mat_h(distribution);                       // include/dlaf/matrix/matrix.h:86-97
+ *     {
+ *       dlaf::matrix::MatrixMirror<T, Device::GPU, Device::CPU> mat(grid, mat_h, uplo);  // matrix_mirror.h:137-173
+ *       dlaf::cholesky_factorization<Backend::GPU, Device::GPU, T>(grid, uplo, mat.get());
+ *     }                                                                       // include/dlaf/factorization/cholesky.h:39-79
+ *     dlaf::triangular_solver<Backend::GPU, Device::GPU, T>(grid, side, uplo, op, diag, alpha, a, b);
+ *                                                                             // include/dlaf/solver/triangular.h:41-177
+ *
+ * What differs from the reference, by design: there is no pika runtime (the calls are blocking, no pika::wait),
+ * Backend::MC does not exist (the library has no CPU path: static_assert), Matrix<T, Device::CPU> stores its
+ * local part column-major with ld = the local row count rounded up to 64 (matrix.h:86-97) or wraps a caller's
+ * pointer, Matrix<T, Device::GPU> is the device-resident tile-layout matrix of the library.  Precondition
+ * failures terminate, like DLAF_ASSERT.  C++17, depends on the C headers only. */
+#pragma once
+
+#include <algorithm>
+#include <complex>
+#include <cstddef>
+#include <cstdio>
+#include <exception>
+#include <functional>
+#include <memory>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include <dlaf_c/desc.h>
+#include <dlaf_c/factorization/cholesky.h>
+#include <dlaf_c/grid.h>
+#include <dlaf_c/init.h>
+#include <dlaf_mi355x/dlaf_mi355x.h>
+
+namespace dlaf {
+
+using SizeType = std::ptrdiff_t;  // include/dlaf/types.h:25
+
+enum class Backend { MC, GPU, Default = GPU };   // types.h:31-37 (MC has no implementation in this library)
+enum class Device { CPU, GPU, Default = GPU };   // types.h:39-45
+
+namespace blas {
+enum class Uplo : char { Upper = 'U', Lower = 'L', General = 'G' };
+enum class Side : char { Left = 'L', Right = 'R' };
+enum class Op : char { NoTrans = 'N', Trans = 'T', ConjTrans = 'C' };
+enum class Diag : char { NonUnit = 'N', Unit = 'U' };
+}  // namespace blas
+
+namespace common {
+enum class Ordering { RowMajor, ColumnMajor };  // common/index2d.h:26
+}
+
+namespace internal {
+[[noreturn]] inline void fail(const char* what) {
+  std::fprintf(stderr, "[dlaf] precondition failed: %s\n", what);
+  std::terminate();
+}
+template <class T>
+constexpr char type_tag() {
+  if constexpr (std::is_same_v<T, float>)
+    return 's';
+  else if constexpr (std::is_same_v<T, double>)
+    return 'd';
+  else if constexpr (std::is_same_v<T, std::complex<float>>)
+    return 'c';
+  else {
+    static_assert(std::is_same_v<T, std::complex<double>>, "element type must be float, double or their complex");
+    return 'z';
+  }
+}
+}  // namespace internal
+
+// ---- 2-D index / size helpers (common/index2d.h, matrix/index.h) ---------------------------------------------
+template <class Tag>
+struct Size2DT {
+  SizeType r = 0, c = 0;
+  Size2DT() = default;
+  Size2DT(SizeType rows_, SizeType cols_) : r(rows_), c(cols_) {}
+  SizeType rows() const { return r; }
+  SizeType cols() const { return c; }
+  bool isEmpty() const { return r == 0 || c == 0; }
+};
+template <class Tag>
+struct Index2DT {
+  SizeType r = 0, c = 0;
+  Index2DT() = default;
+  Index2DT(SizeType row_, SizeType col_) : r(row_), c(col_) {}
+  SizeType row() const { return r; }
+  SizeType col() const { return c; }
+};
+struct GlobalElementTag;
+struct LocalElementTag;
+struct TileElementTag;
+struct GridTag;
+using GlobalElementSize = Size2DT<GlobalElementTag>;
+using LocalElementSize = Size2DT<LocalElementTag>;
+using TileElementSize = Size2DT<TileElementTag>;
+using GlobalElementIndex = Index2DT<GlobalElementTag>;
+using LocalElementIndex = Index2DT<LocalElementTag>;
+namespace comm {
+using Size2D = Size2DT<GridTag>;
+using Index2D = Index2DT<GridTag>;
+
+// communication/communicator_grid.h:37-153.  Owns a grid context of the library.
+class CommunicatorGrid {
+public:
+  // MPI-free constructors (the library's own grid entry points)
+  static CommunicatorGrid single() { return CommunicatorGrid(dlaf_mi355x_create_grid_single()); }
+  static CommunicatorGrid rccl(const void* unique_id128, int nranks, int rank, int rows, int cols,
+                               common::Ordering ordering) {
+    return CommunicatorGrid(dlaf_mi355x_create_grid_rccl(unique_id128, nranks, rank, rows, cols,
+                                                        ordering == common::Ordering::ColumnMajor ? 'C' : 'R'));
+  }
+#ifdef DLAF_MI355X_WITH_MPI
+  // the reference's constructor (communicator_grid.h:41): needs libdlaf_mi355x_mpi.so
+  CommunicatorGrid(MPI_Comm comm, int rows, int cols, common::Ordering ordering)
+      : CommunicatorGrid(dlaf_create_grid(comm, rows, cols, ordering == common::Ordering::ColumnMajor ? 'C' : 'R')) {}
+#endif
+  // adopts an existing context (e.g. from dlaf_create_grid); freed on destruction
+  explicit CommunicatorGrid(int context) : ctx_(context) {
+    int pr = 0, pc = 0, mr = 0, mc = 0;
+    if (context < 0 || dlaf_mi355x_grid_info(context, &pr, &pc, &mr, &mc) != 0)
+      internal::fail("valid grid context");
+    size_ = Size2D(pr, pc);
+    rank_ = Index2D(mr, mc);
+  }
+  CommunicatorGrid(CommunicatorGrid&& o) noexcept : ctx_(o.ctx_), size_(o.size_), rank_(o.rank_) { o.ctx_ = -1; }
+  CommunicatorGrid(const CommunicatorGrid&) = delete;
+  CommunicatorGrid& operator=(const CommunicatorGrid&) = delete;
+  ~CommunicatorGrid() {
+    if (ctx_ >= 0)
+      dlaf_free_grid(ctx_);
+  }
+  Index2D rank() const { return rank_; }
+  Size2D size() const { return size_; }
+  int context() const { return ctx_; }
+  void wait_all_communicators() const { dlaf_mi355x_grid_barrier(ctx_); }
+
+private:
+  int ctx_ = -1;
+  Size2D size_;
+  Index2D rank_;
+};
+}  // namespace comm
+
+namespace matrix {
+
+// matrix/distribution.h: global size, block size, process grid, this process, source process
+class Distribution {
+public:
+  Distribution() = default;
+  Distribution(const LocalElementSize& size, const TileElementSize& block)
+      : size_(size.rows(), size.cols()), block_(block), grid_(1, 1), rank_(0, 0), src_(0, 0) {}
+  Distribution(const GlobalElementSize& size, const TileElementSize& block, const comm::Size2D& grid_size,
+               const comm::Index2D& rank, const comm::Index2D& source_rank)
+      : size_(size), block_(block), grid_(grid_size), rank_(rank), src_(source_rank) {
+    if (block.rows() < 1 || block.cols() < 1)
+      internal::fail("block size >= 1");
+  }
+  const GlobalElementSize& size() const { return size_; }
+  const TileElementSize& block_size() const { return block_; }
+  const comm::Size2D& grid_size() const { return grid_; }
+  const comm::Index2D& rank_index() const { return rank_; }
+  const comm::Index2D& source_rank_index() const { return src_; }
+  LocalElementSize local_size() const {
+    return LocalElementSize(dlaf_mi355x_dist_local_size(size_.rows(), (int) block_.rows(), (int) grid_.rows(),
+                                                        (int) rank_.row(), (int) src_.row()),
+                            dlaf_mi355x_dist_local_size(size_.cols(), (int) block_.cols(), (int) grid_.cols(),
+                                                        (int) rank_.col(), (int) src_.col()));
+  }
+  // global element index of local element (i, j) (util_distribution.h:82-196)
+  GlobalElementIndex global_element_index(const LocalElementIndex& l) const {
+    auto one = [](SizeType li, SizeType nb, SizeType P, SizeType rank, SizeType src) {
+      const SizeType lt = li / nb;
+      return (lt * P + (rank + P - src) % P) * nb + li % nb;
+    };
+    return GlobalElementIndex(one(l.row(), block_.rows(), grid_.rows(), rank_.row(), src_.row()),
+                              one(l.col(), block_.cols(), grid_.cols(), rank_.col(), src_.col()));
+  }
+
+private:
+  GlobalElementSize size_;
+  TileElementSize block_{1, 1};
+  comm::Size2D grid_{1, 1};
+  comm::Index2D rank_, src_;
+};
+
+}  // namespace matrix
+
+template <class T, Device D>
+class Matrix;
+
+// Host matrix: the local part of a block-cyclic matrix, column-major (ScaLAPACK local layout).
+template <class T>
+class Matrix<T, Device::CPU> {
+public:
+  using ElementType = T;
+  Matrix(const LocalElementSize& size, const TileElementSize& block) : Matrix(matrix::Distribution(size, block)) {}
+  explicit Matrix(matrix::Distribution dist) : dist_(std::move(dist)) {
+    const LocalElementSize ls = dist_.local_size();
+    ld_ = std::max<SizeType>(1, (ls.rows() + 63) / 64 * 64);  // matrix.h:86-97
+    own_.assign((std::size_t) ld_ * (std::size_t) std::max<SizeType>(1, ls.cols()), T{});
+    ptr_ = own_.data();
+  }
+  // wraps the caller's memory (matrix.h:137-138: Matrix(distribution, layout, ptr))
+  Matrix(matrix::Distribution dist, T* ptr, SizeType ld) : dist_(std::move(dist)), ptr_(ptr), ld_(ld) {}
+  const matrix::Distribution& distribution() const { return dist_; }
+  GlobalElementSize size() const { return dist_.size(); }
+  TileElementSize block_size() const { return dist_.block_size(); }
+  T* ptr() { return ptr_; }
+  const T* ptr() const { return ptr_; }
+  SizeType ld() const { return ld_; }
+  T& operator()(const LocalElementIndex& i) { return ptr_[i.row() + i.col() * ld_]; }
+  const T& operator()(const LocalElementIndex& i) const { return ptr_[i.row() + i.col() * ld_]; }
+
+private:
+  matrix::Distribution dist_;
+  std::vector<T> own_;
+  T* ptr_ = nullptr;
+  SizeType ld_ = 1;
+};
+
+// Device matrix: resident in HBM in the library's tile layout (created through a MatrixMirror or empty).
+template <class T>
+class Matrix<T, Device::GPU> {
+public:
+  using ElementType = T;
+  Matrix(const comm::CommunicatorGrid& grid, matrix::Distribution dist, blas::Uplo uplo)
+      : dist_(std::move(dist)), uplo_(uplo), ctx_(grid.context()) {
+    const auto sz = dist_.size();
+    const auto bs = dist_.block_size();
+    if (sz.rows() != sz.cols() || bs.rows() != bs.cols())
+      internal::fail("device matrices of this library are square with square blocks");
+    DLAF_descriptor d{(int) sz.rows(), (int) sz.cols(), (int) bs.rows(), (int) bs.cols(),
+                      (int) dist_.source_rank_index().row(), (int) dist_.source_rank_index().col(), 0, 0, 1};
+    if (dlaf_mi355x_matrix_create(ctx_, internal::type_tag<T>(), (char) uplo, d, &h_) != 0)
+      internal::fail("dlaf_mi355x_matrix_create");
+  }
+  Matrix(Matrix&& o) noexcept : dist_(o.dist_), uplo_(o.uplo_), ctx_(o.ctx_), h_(o.h_) { o.h_ = nullptr; }
+  Matrix(const Matrix&) = delete;
+  ~Matrix() {
+    if (h_)
+      dlaf_mi355x_matrix_destroy(h_);
+  }
+  const matrix::Distribution& distribution() const { return dist_; }
+  GlobalElementSize size() const { return dist_.size(); }
+  TileElementSize block_size() const { return dist_.block_size(); }
+  blas::Uplo uplo() const { return uplo_; }
+  dlaf_mi355x_matrix_t handle() const { return h_; }
+  int context() const { return ctx_; }
+
+private:
+  matrix::Distribution dist_;
+  blas::Uplo uplo_;
+  int ctx_;
+  dlaf_mi355x_matrix_t h_ = nullptr;
+};
+
+namespace matrix {
+
+// matrix/matrix_mirror.h:137-173: copies the source to the target device on construction and back on
+// destruction (copyTargetToSource / copySourceToTarget on demand).  The uplo triangle is what travels, as in
+// the Cholesky path; `uplo` must therefore be given (the reference mirrors whole matrices).
+template <class T, Device Target, Device Source>
+class MatrixMirror;
+
+template <class T>
+class MatrixMirror<T, Device::GPU, Device::CPU> {
+public:
+  MatrixMirror(const comm::CommunicatorGrid& grid, Matrix<T, Device::CPU>& source, blas::Uplo uplo)
+      : src_(source), dev_(grid, source.distribution(), uplo) {
+    copySourceToTarget();
+  }
+  ~MatrixMirror() { copyTargetToSource(); }
+  Matrix<T, Device::GPU>& get() { return dev_; }
+  void copySourceToTarget() {
+    if (dlaf_mi355x_matrix_upload(dev_.handle(), src_.ptr(), (int) src_.ld()) != 0)
+      internal::fail("dlaf_mi355x_matrix_upload");
+  }
+  void copyTargetToSource() {
+    if (dlaf_mi355x_matrix_download(dev_.handle(), src_.ptr(), (int) src_.ld()) != 0)
+      internal::fail("dlaf_mi355x_matrix_download");
+  }
+
+private:
+  Matrix<T, Device::CPU>& src_;
+  Matrix<T, Device::GPU> dev_;
+};
+
+namespace util {
+// matrix/util_matrix.h:148-160 (set): el(GlobalElementIndex) for every local element
+template <class T, class ElementGetter>
+void set(Matrix<T, Device::CPU>& m, ElementGetter&& el) {
+  const LocalElementSize ls = m.distribution().local_size();
+  for (SizeType j = 0; j < ls.cols(); ++j)
+    for (SizeType i = 0; i < ls.rows(); ++i)
+      m(LocalElementIndex(i, j)) = el(m.distribution().global_element_index(LocalElementIndex(i, j)));
+}
+// util_matrix.h:498-501
+template <class T>
+void set_random_hermitian_positive_definite(const comm::CommunicatorGrid& grid, Matrix<T, Device::CPU>& m) {
+  const auto& d = m.distribution();
+  DLAF_descriptor desc{(int) d.size().rows(), (int) d.size().cols(), (int) d.block_size().rows(),
+                       (int) d.block_size().cols(), (int) d.source_rank_index().row(),
+                       (int) d.source_rank_index().col(), 0, 0, (int) m.ld()};
+  if (dlaf_mi355x_set_random_hpd(grid.context(), internal::type_tag<T>(), m.ptr(), desc, 0) != 0)
+    internal::fail("square matrix with square blocks");
+}
+}  // namespace util
+}  // namespace matrix
+
+// ---- the algorithms ------------------------------------------------------------------------------------------
+// include/dlaf/factorization/cholesky.h:67-79.  Device-resident: factors in HBM, nothing crosses PCIe.
+template <Backend B, Device D, class T>
+void cholesky_factorization(comm::CommunicatorGrid& grid, blas::Uplo uplo, Matrix<T, Device::GPU>& mat) {
+  static_assert(B == Backend::GPU && D == Device::GPU, "this library implements Backend::GPU on Device::GPU only");
+  if (uplo != mat.uplo())
+    internal::fail("uplo of the call equals the uplo the device matrix was created with");
+  if (grid.context() != mat.context())
+    internal::fail("matrix::equal_process_grid(mat_a, grid)");
+  const int info = dlaf_mi355x_cholesky_factorization_device(mat.handle());
+  if (info != 0) {
+    // the reference aborts in the tile kernel (lapack/tile.h:374-378, src/cusolver/assert_info.cu:35-45)
+    std::fprintf(stderr, "[dlaf] cholesky_factorization: the leading minor of order %d is not positive definite\n", info);
+    std::terminate();
+  }
+}
+// Host-resident local part (what the C wrapper does around the template, src/c_api/factorization/cholesky.h:44-55)
+template <Backend B, Device D, class T>
+void cholesky_factorization(comm::CommunicatorGrid& grid, blas::Uplo uplo, Matrix<T, Device::CPU>& mat) {
+  static_assert(B == Backend::GPU, "this library has no CPU backend");
+  matrix::MatrixMirror<T, Device::GPU, Device::CPU> mirror(grid, mat, uplo);
+  cholesky_factorization<Backend::GPU, Device::GPU, T>(grid, uplo, mirror.get());
+}
+
+// include/dlaf/factorization/cholesky.h:39-50: the local (one process) overloads
+template <Backend B, Device D, class T>
+void cholesky_factorization(blas::Uplo uplo, Matrix<T, Device::CPU>& mat) {
+  comm::CommunicatorGrid grid = comm::CommunicatorGrid::single();
+  cholesky_factorization<B, D, T>(grid, uplo, mat);
+}
+
+// include/dlaf/solver/triangular.h:109-177 (host-resident operands)
+template <Backend B, Device D, class T>
+void triangular_solver(comm::CommunicatorGrid& grid, blas::Side side, blas::Uplo uplo, blas::Op op, blas::Diag diag,
+                       T alpha, Matrix<T, Device::CPU>& mat_a, Matrix<T, Device::CPU>& mat_b) {
+  static_assert(B == Backend::GPU, "this library has no CPU backend");
+  auto desc_of = [](const Matrix<T, Device::CPU>& m) {
+    const auto& d = m.distribution();
+    return DLAF_descriptor{(int) d.size().rows(), (int) d.size().cols(), (int) d.block_size().rows(),
+                           (int) d.block_size().cols(), (int) d.source_rank_index().row(),
+                           (int) d.source_rank_index().col(), 0, 0, (int) m.ld()};
+  };
+  int r;
+  if constexpr (std::is_same_v<T, float>)
+    r = dlaf_mi355x_triangular_solver_s(grid.context(), (char) side, (char) uplo, (char) op, (char) diag, &alpha,
+                                        mat_a.ptr(), desc_of(mat_a), mat_b.ptr(), desc_of(mat_b));
+  else if constexpr (std::is_same_v<T, double>)
+    r = dlaf_mi355x_triangular_solver_d(grid.context(), (char) side, (char) uplo, (char) op, (char) diag, &alpha,
+                                        mat_a.ptr(), desc_of(mat_a), mat_b.ptr(), desc_of(mat_b));
+  else if constexpr (std::is_same_v<T, std::complex<float>>)
+    r = dlaf_mi355x_triangular_solver_c(grid.context(), (char) side, (char) uplo, (char) op, (char) diag, &alpha,
+                                        mat_a.ptr(), desc_of(mat_a), mat_b.ptr(), desc_of(mat_b));
+  else
+    r = dlaf_mi355x_triangular_solver_z(grid.context(), (char) side, (char) uplo, (char) op, (char) diag, &alpha,
+                                        mat_a.ptr(), desc_of(mat_a), mat_b.ptr(), desc_of(mat_b));
+  if (r != 0)
+    internal::fail("triangular_solver");
+}
+
+// include/dlaf/solver/triangular.h:41-107: the local overload
+template <Backend B, Device D, class T>
+void triangular_solver(blas::Side side, blas::Uplo uplo, blas::Op op, blas::Diag diag, T alpha,
+                       Matrix<T, Device::CPU>& mat_a, Matrix<T, Device::CPU>& mat_b) {
+  comm::CommunicatorGrid grid = comm::CommunicatorGrid::single();
+  triangular_solver<B, D, T>(grid, side, uplo, op, diag, alpha, mat_a, mat_b);
+}
+
+// include/dlaf/init.h: the library needs no runtime arguments; initialize / finalize are idempotent
+inline void initialize(int argc = 0, const char** argv = nullptr) { dlaf_initialize(argc, argv, 0, nullptr); }
+inline void finalize() { dlaf_finalize(); }
+
+}  // namespace dlaf
