@@ -29,3 +29,65 @@ def test_reference_style_cpp_tests_on_the_facade():
     r = subprocess.run([build()], cwd=ROOT, capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, DLAF_MI355X_DEVICE="0"))
     assert r.returncode == 0 and "CPP_API_TEST OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+MINI_SRC = os.path.join(ROOT, "miniapp", "miniapp_cholesky.cpp")
+MINI_EXE = os.path.join(ROOT, "miniapp", "miniapp_cholesky")
+MINI_MPI = os.path.join(ROOT, "miniapp", "miniapp_cholesky_mpi")
+
+
+def build_miniapp(mpi=False):
+    exe = MINI_MPI if mpi else MINI_EXE
+    newest = max(os.path.getmtime(MINI_SRC), os.path.getmtime(os.path.join(ROOT, "include", "dlaf_mi355x", "dlaf.hpp")))
+    if os.path.exists(exe) and os.path.getmtime(exe) >= newest:
+        return exe
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), MINI_SRC, "-L", LIB]
+    if mpi:
+        import test_c_api
+        test_c_api.build("test_grid_mpi")   # makes sure the MPI shim and its private link directory exist
+        inc = os.path.join(os.path.dirname(os.path.dirname(test_c_api.MPICC)), "include")
+        cmd += ["-DDLAF_MI355X_WITH_MPI", "-I", inc, "-L", os.path.join(LIB, "mpi"), "-ldlaf_mi355x_mpi", "-lmpi",
+                f"-Wl,-rpath-link,{LIB}/mpi", f"-Wl,-rpath,{LIB}/mpi"]
+    cmd += ["-ldlaf_mi355x", f"-Wl,-rpath,{LIB}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    subprocess.run(cmd, check=True)
+    return exe
+
+
+def test_miniapp_compiles():
+    assert os.path.exists(build_miniapp())
+
+
+def check_miniapp_output(out, nruns, nchecks):
+    import re
+    runs = re.findall(r"^\[(\d+)\] ([0-9.e+-]+)s ([0-9.e+-]+)GFlop/s (\w+) \((\d+), (\d+)\) \((\d+), (\d+)\) \((\d+), (\d+)\) 1 GPU$",
+                      out, flags=re.M)
+    assert len(runs) == nruns, out
+    assert all(float(r[2]) > 0 for r in runs)
+    assert out.count("CSVData-2, run, ") == nruns
+    checks = re.findall(r"^(ERROR: |Warning: )?Max Diff / Max A: ([0-9.e+-]+)$", out, flags=re.M)
+    assert len(checks) == nchecks and all(c[0] == "" for c in checks), out
+
+
+@pytest.mark.gpu
+def test_miniapp_cholesky_reference_cli_and_output():
+    exe = build_miniapp()
+    for t, uplo in (("d", "L"), ("z", "U")):
+        r = subprocess.run([exe, "--matrix-size", "2048", "--block-size=256", "--nruns", "2", "--nwarmups", "1", "--type", t,
+                            "--uplo", uplo, "--check-result", "all", "--csv"], cwd=ROOT, capture_output=True, text=True,
+                           timeout=600, env=dict(os.environ, DLAF_MI355X_DEVICE="0"))
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        check_miniapp_output(r.stdout, 2, 3)   # "all" also checks the warm-up run, as upstream does
+
+
+@pytest.mark.gpu
+def test_miniapp_cholesky_mpi_grid():
+    import test_c_api
+    exe = build_miniapp(mpi=True)
+    env = dict(os.environ, DLAF_MI355X_MPI_TRANSPORT="host", DLAF_MI355X_DEVICE="0", OMP_NUM_THREADS="1")
+    env.pop("LOCAL_RANK", None)
+    r = subprocess.run([test_c_api.MPIEXEC, "-n", "4", exe, "--matrix-size", "1500", "--block-size", "128", "--grid-rows", "2",
+                        "--grid-cols", "2", "--nruns", "2", "--check-result", "last", "--csv"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert r.stdout.count("GFlop/s d") == 2 and "(2, 2)" in r.stdout and "ERROR" not in r.stdout and \
+        r.stdout.count("Max Diff / Max A") == 1, r.stdout
