@@ -113,7 +113,7 @@ int cholesky_host(int ctx, char uplo, HT* a, const DLAF_descriptor& d) {
   m.upload(reinterpret_cast<const DT*>(a), d.ld);
   const int info = m.factorize();
   if (info == 0)
-    m.download(reinterpret_cast<DT*>(a), d.ld);
+    m.download(reinterpret_cast<DT*>(a), d.ld, /*staging_is_current=*/true);
   return info;
 }
 

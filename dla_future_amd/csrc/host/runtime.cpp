@@ -295,6 +295,38 @@ static void ensure_staging(DeviceMatrix<T>& m, size_t elems) {
   m.staging_elems = elems;
 }
 
+// The uplo triangle of the caller's local array as one rectangle per local tile column of the SOURCE:
+// f(row0, nrows, col0, ncols) in source element coordinates; diag(row0, col0, rows, cols) for every local
+// diagonal tile (whose other half lies inside a rectangle but is not part of the triangle).
+template <class T, class F, class D>
+static void for_each_triangle_block(const DeviceMatrix<T>& m, F&& f, D&& diag) {
+  long srows, scols;
+  source_extents(m, srows, scols);
+  // source axes: rows of the source are the view's rows (uplo L) or the view's columns (uplo U)
+  const Axis& srow_ax = m.transposed ? m.cols : m.rows;
+  const Axis& scol_ax = m.transposed ? m.rows : m.cols;
+  const long nlc = scol_ax.local_tiles();
+  for (long jl = 0; jl < nlc; ++jl) {
+    const long gj = scol_ax.global_of(jl);
+    const long col0 = jl * m.nb, ncols = std::min<long>(m.nb, scols - col0);
+    long row0, row1;
+    if (!m.transposed) {  // lower: source tile rows with global index >= gj
+      row0 = std::min(srow_ax.next_local(gj) * m.nb, srows);
+      row1 = srows;
+    }
+    else {  // upper: source tile rows with global index <= gj
+      row0 = 0;
+      row1 = std::min(srow_ax.next_local(gj + 1) * m.nb, srows);
+    }
+    if (ncols > 0 && row1 > row0)
+      f(row0, row1 - row0, col0, ncols);
+    if (srow_ax.mine(gj)) {
+      const long r0 = srow_ax.local_of(gj) * m.nb;
+      diag(r0, col0, std::min<long>(m.nb, srows - r0), ncols);
+    }
+  }
+}
+
 template <class T>
 void DeviceMatrix<T>::upload(const T* host, long ld) {
   long srows, scols;
@@ -303,26 +335,49 @@ void DeviceMatrix<T>::upload(const T* host, long ld) {
     return;
   const long lds = srows;
   ensure_staging(*this, (size_t) lds * scols);
-  DLAF_HIP_CHECK(hipMemcpy2DAsync(staging, (size_t) lds * sizeof(T), host, (size_t) ld * sizeof(T),
-                                  (size_t) srows * sizeof(T), (size_t) scols, hipMemcpyHostToDevice, s_high));
+  // only the uplo triangle crosses PCIe (the relayout never reads the other one)
+  for_each_triangle_block(
+      *this,
+      [&](long r0, long nr, long c0, long nc) {
+        DLAF_HIP_CHECK(hipMemcpy2DAsync(staging + r0 + c0 * lds, (size_t) lds * sizeof(T), host + r0 + c0 * ld,
+                                        (size_t) ld * sizeof(T), (size_t) nr * sizeof(T), (size_t) nc,
+                                        hipMemcpyHostToDevice, s_high));
+      },
+      [](long, long, long, long) {});
   launch_to_tiles(layout_args(*this, staging, lds), s_high);
   DLAF_HIP_CHECK(hipStreamSynchronize(s_high));
 }
 
 template <class T>
-void DeviceMatrix<T>::download(T* host, long ld) {
+void DeviceMatrix<T>::download(T* host, long ld, bool staging_is_current) {
   long srows, scols;
   source_extents(*this, srows, scols);
   if (srows == 0 || scols == 0)
     return;
   const long lds = srows;
   ensure_staging(*this, (size_t) lds * scols);
-  // the untouched triangle must come back unchanged: stage the caller's current content first
-  DLAF_HIP_CHECK(hipMemcpy2DAsync(staging, (size_t) lds * sizeof(T), host, (size_t) ld * sizeof(T),
-                                  (size_t) srows * sizeof(T), (size_t) scols, hipMemcpyHostToDevice, s_high));
+  // The other half of the diagonal tiles travels back inside the rectangles and must come back unchanged:
+  // it is already in the staging copy when that was filled from this very array and no caller code ran in
+  // between (the blocking host entry points say so), otherwise the diagonal tiles are staged first.
+  if (!staging_is_current) {
+    for_each_triangle_block(
+        *this, [](long, long, long, long) {},
+        [&](long r0, long c0, long nr, long nc) {
+          if (nr > 0 && nc > 0)
+            DLAF_HIP_CHECK(hipMemcpy2DAsync(staging + r0 + c0 * lds, (size_t) lds * sizeof(T), host + r0 + c0 * ld,
+                                            (size_t) ld * sizeof(T), (size_t) nr * sizeof(T), (size_t) nc,
+                                            hipMemcpyHostToDevice, s_high));
+        });
+  }
   launch_from_tiles(layout_args(*this, staging, lds), s_high);
-  DLAF_HIP_CHECK(hipMemcpy2DAsync(host, (size_t) ld * sizeof(T), staging, (size_t) lds * sizeof(T),
-                                  (size_t) srows * sizeof(T), (size_t) scols, hipMemcpyDeviceToHost, s_high));
+  for_each_triangle_block(
+      *this,
+      [&](long r0, long nr, long c0, long nc) {
+        DLAF_HIP_CHECK(hipMemcpy2DAsync(host + r0 + c0 * ld, (size_t) ld * sizeof(T), staging + r0 + c0 * lds,
+                                        (size_t) lds * sizeof(T), (size_t) nr * sizeof(T), (size_t) nc,
+                                        hipMemcpyDeviceToHost, s_high));
+      },
+      [](long, long, long, long) {});
   DLAF_HIP_CHECK(hipStreamSynchronize(s_high));
 }
 

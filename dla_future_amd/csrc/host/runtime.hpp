@@ -130,7 +130,9 @@ struct DeviceMatrix : MatrixBase {
   ~DeviceMatrix() override { destroy(); }
 
   void upload(const T* host, long ld);     // caller's local column-major array -> tiles
-  void download(T* host, long ld);         // tiles -> caller's array (uplo triangle only)
+  // tiles -> caller's array (uplo triangle only).  staging_is_current: the staging copy was filled by upload()
+  // from this same array and the caller has not run since (saves re-staging the diagonal tiles)
+  void download(T* host, long ld, bool staging_is_current = false);
   void copy_from(const DeviceMatrix<T>& other);
   // Checker (miniapp/miniapp_cholesky.cpp:408-443): `this` holds the ORIGINAL matrix and is overwritten
   // with A - L L^H on the uplo triangle; returns max|A - L L^H| and max|A| over the whole grid.
