@@ -36,8 +36,13 @@ MINI_EXE = os.path.join(ROOT, "miniapp", "miniapp_cholesky")
 MINI_MPI = os.path.join(ROOT, "miniapp", "miniapp_cholesky_mpi")
 
 
-def build_miniapp(mpi=False):
-    exe = MINI_MPI if mpi else MINI_EXE
+def build_miniapp(mpi=False, name="miniapp_cholesky"):
+    src = os.path.join(ROOT, "miniapp", name + ".cpp")
+    exe = os.path.join(ROOT, "miniapp", name + ("_mpi" if mpi else ""))
+    return _build_miniapp(src, exe, mpi)
+
+
+def _build_miniapp(MINI_SRC, exe, mpi):
     newest = max(os.path.getmtime(MINI_SRC), os.path.getmtime(os.path.join(ROOT, "include", "dlaf_mi355x", "dlaf.hpp")))
     if os.path.exists(exe) and os.path.getmtime(exe) >= newest:
         return exe
@@ -55,6 +60,7 @@ def build_miniapp(mpi=False):
 
 def test_miniapp_compiles():
     assert os.path.exists(build_miniapp())
+    assert os.path.exists(build_miniapp(name="miniapp_triangular_solver"))
 
 
 def check_miniapp_output(out, nruns, nchecks):
@@ -91,3 +97,17 @@ def test_miniapp_cholesky_mpi_grid():
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert r.stdout.count("GFlop/s d") == 2 and "(2, 2)" in r.stdout and "ERROR" not in r.stdout and \
         r.stdout.count("Max Diff / Max A") == 1, r.stdout
+
+
+@pytest.mark.gpu
+def test_miniapp_triangular_solver():
+    import re
+    exe = build_miniapp(name="miniapp_triangular_solver")
+    r = subprocess.run([exe, "--m", "1500", "--n", "700", "--mb", "128", "--nb", "128", "--side", "L", "--uplo", "L", "--op", "N",
+                        "--nruns", "2"], cwd=ROOT, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, DLAF_MI355X_DEVICE="0"))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert len(re.findall(r"^\[\d+\] [0-9.e+-]+s [0-9.e+-]+GFlop/s dLLNN \(1500, 700\) \(128, 128\) \(1, 1\) 1 GPU", r.stdout,
+                          flags=re.M)) == 2, r.stdout
+    resid = float(re.search(r"corner: ([0-9.e+-]+)", r.stdout).group(1))
+    assert resid < 1e-11, r.stdout
