@@ -161,6 +161,27 @@ def test_bad_descriptor_terminates_like_upstream():
     assert r.returncode != 0 and "survived" not in r.stdout and "sub-matrices are not supported" in r.stderr
 
 
+@pytest.mark.parametrize("mutate,needle", [
+    ("side = 'X'", "bad side/uplo/op/diag"),
+    ("db.mb = 3", "B's blocks"),
+    ("da.n = 5", "A must be square"),
+    ("db.m = 7", "A is 6 x 6, B is 7 x 4"),
+    ("db.isrc = 3", "outside the 1 x 1 grid"),
+])
+def test_triangular_solver_preconditions_terminate(mutate, needle):
+    """include/dlaf/solver/triangular.h:43-57 / :93-107 assert their preconditions; so does this entry, before it
+    touches the GPU (the checks run on a box without one)."""
+    r = _run("import numpy as np, ctypes as C, dla_future_amd as d\n"
+             "from dla_future_amd.capi import lib, DLAFDescriptor\n"
+             "g = d.Grid.single(); a = np.eye(6, order='F'); b = np.ones((6, 4), order='F'); al = np.array([1.0])\n"
+             "da = DLAFDescriptor(6, 6, 2, 2, 0, 0, 0, 0, 6); db = DLAFDescriptor(6, 4, 2, 2, 0, 0, 0, 0, 6); side = 'L'\n"
+             f"{mutate}\n"
+             "lib().dlaf_mi355x_triangular_solver_d(g.context, side.encode(), b'L', b'N', b'N', al.ctypes.data, "
+             "a.ctypes.data, da, b.ctypes.data, db)\n"
+             "print('survived')")
+    assert r.returncode != 0 and "survived" not in r.stdout and needle in r.stderr, (r.stdout, r.stderr[-500:])
+
+
 def test_missing_library_fails_loudly():
     r = _run("import dla_future_amd.capi as c\n"
              "c.lib_path = lambda: '/nonexistent/libdlaf_mi355x.so'\n"
