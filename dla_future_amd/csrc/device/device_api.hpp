@@ -128,6 +128,8 @@ struct LayoutArgs {
   // only: scale != 0 multiplies by alpha (the solver's alpha * B)
   int full = 0, conj = 0, scale = 0;
   T alpha{};
+  // restrict the move to view tile columns [jl_first, jl_first + jl_count) (jl_count 0: to the last one)
+  int jl_first = 0, jl_count = 0;
 };
 template <class T>
 void launch_to_tiles(const LayoutArgs<T>& args, hipStream_t stream);

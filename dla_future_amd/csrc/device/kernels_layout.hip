@@ -19,7 +19,7 @@ constexpr int kLT = 32;
 template <class T, bool TO_TILES>
 __global__ __launch_bounds__(kThreads) void layout_kernel(LayoutArgs<T> p, int sb) {
   __shared__ T buf[kLT][kLT + 1];
-  const int il = blockIdx.y, jl = blockIdx.z;
+  const int il = blockIdx.y, jl = (int) blockIdx.z + p.jl_first;
   const int gi = il * p.pr + p.ri, gj = jl * p.pc + p.ci;
   if (!p.full && gi < gj)
     return;
@@ -98,7 +98,10 @@ static void launch_layout(const LayoutArgs<T>& a, hipStream_t stream) {
   if (a.ltr <= 0 || a.ltc <= 0 || a.nb <= 0)
     return;
   const int sb = (a.nb + kLT - 1) / kLT;
-  dim3 grid((unsigned) (sb * sb), (unsigned) a.ltr, (unsigned) a.ltc);
+  const int ncols = a.jl_count > 0 ? a.jl_count : a.ltc - a.jl_first;
+  if (ncols <= 0)
+    return;
+  dim3 grid((unsigned) (sb * sb), (unsigned) a.ltr, (unsigned) ncols);
   hipLaunchKernelGGL((layout_kernel<T, TO_TILES>), grid, dim3(kThreads), 0, stream, a, sb);
 }
 

@@ -111,10 +111,8 @@ int cholesky_host(int ctx, char uplo, HT* a, const DLAF_descriptor& d) {
   DeviceMatrix<DT> m;
   m.create(&g, uplo, d.m, d.nb, d.isrc, d.jsrc);
   m.upload(reinterpret_cast<const DT*>(a), d.ld);
-  const int info = m.factorize();
-  if (info == 0)
-    m.download(reinterpret_cast<DT*>(a), d.ld, /*staging_is_current=*/true);
-  return info;
+  // (a matrix that is not positive definite comes back partially overwritten, as from LAPACK)
+  return m.factorize_and_download(reinterpret_cast<DT*>(a), d.ld);
 }
 
 template <class HT>

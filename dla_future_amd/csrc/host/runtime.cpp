@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstring>
 #include <exception>
+#include <thread>
 
 namespace dlaf_mi355x {
 
@@ -759,6 +760,7 @@ void DeviceMatrix<T>::factorize_async() {
       if (in_col)
         trsm(il_t, ltr, klc, Lkk, Wkk, kb);
       DLAF_HIP_CHECK(hipEventRecord(ev_panel[k], s_main));
+      panels_issued.store(k, std::memory_order_release);
 
       // ---- s_comm: head, tail along process rows; transposed panel along process columns -----------
       Step cur;
@@ -851,6 +853,7 @@ void DeviceMatrix<T>::factorize_async() {
       if (in_col)
         trsm(il_n, ltr, klc, Lkk, Wkk, kb);
       DLAF_HIP_CHECK(hipEventRecord(ev_panel[k], s_main));
+      panels_issued.store(k, std::memory_order_release);
 
       // ---- s_comm: panel along process rows, transposed panel along process columns ----------------
       Step cur;
@@ -1100,6 +1103,84 @@ template <class T>
 int DeviceMatrix<T>::factorize() {
   factorize_async();
   return wait();
+}
+
+// View tile column k (rows on/below the diagonal) as a rectangle of the caller's local array.
+template <class T>
+static bool view_column_rect(const DeviceMatrix<T>& m, long k, long& r0, long& nr, long& c0, long& nc) {
+  if (!m.cols.mine(k))
+    return false;
+  long srows, scols;
+  source_extents(m, srows, scols);
+  const long jl = m.cols.local_of(k);
+  const long first = m.rows.next_local(k) * m.nb;  // first view row (element) on/below the diagonal
+  if (!m.transposed) {
+    r0 = std::min(first, srows);
+    nr = srows - r0;
+    c0 = jl * m.nb;
+    nc = std::min<long>(m.nb, scols - c0);
+  }
+  else {  // the view column is a row block of the source
+    r0 = jl * m.nb;
+    nr = std::min<long>(m.nb, srows - r0);
+    c0 = std::min(first, scols);
+    nc = scols - c0;
+  }
+  return nr > 0 && nc > 0;
+}
+
+template <class T>
+int DeviceMatrix<T>::factorize_and_download(T* host, long ld) {
+  long srows, scols;
+  source_extents(*this, srows, scols);
+  const char* off = std::getenv("DLAF_MI355X_OVERLAP_DOWNLOAD");
+  if (srows == 0 || scols == 0 || nt < 3 || (off && std::atoi(off) == 0)) {
+    const int r = factorize();
+    if (r == 0)
+      download(host, ld, true);
+    return r;
+  }
+  const long lds = srows;
+  int dev = 0;
+  DLAF_HIP_CHECK(hipGetDevice(&dev));
+  panels_issued.store(-1, std::memory_order_release);
+  std::atomic<bool> stop{false};
+  auto fetch_column = [&](long k, hipStream_t s) {
+    long r0, nr, c0, nc;
+    if (!view_column_rect(*this, k, r0, nr, c0, nc))
+      return;
+    LayoutArgs<T> la = layout_args(*this, staging, lds);
+    la.jl_first = (int) cols.local_of(k);
+    la.jl_count = 1;
+    launch_from_tiles(la, s);
+    DLAF_HIP_CHECK(hipMemcpy2DAsync(host + r0 + c0 * ld, (size_t) ld * sizeof(T), staging + r0 + c0 * lds,
+                                    (size_t) lds * sizeof(T), (size_t) nr * sizeof(T), (size_t) nc,
+                                    hipMemcpyDeviceToHost, s));
+    DLAF_HIP_CHECK(hipStreamSynchronize(s));
+  };
+  // columns 0 .. nt-2 leave as soon as their panel is solved; the helper never touches a column whose event
+  // has not been recorded yet (panels_issued), and the device flag stops it on a failed factorization
+  std::thread helper([&] {
+    DLAF_HIP_CHECK(hipSetDevice(dev));
+    hipStream_t s_dl = nullptr;
+    DLAF_HIP_CHECK(hipStreamCreateWithFlags(&s_dl, hipStreamNonBlocking));
+    for (long k = 0; k + 1 < nt; ++k) {
+      while (panels_issued.load(std::memory_order_acquire) < k && !stop.load(std::memory_order_acquire))
+        std::this_thread::yield();
+      if (panels_issued.load(std::memory_order_acquire) < k)
+        break;
+      DLAF_HIP_CHECK(hipStreamWaitEvent(s_dl, ev_panel[k], 0));
+      fetch_column(k, s_dl);
+    }
+    DLAF_HIP_CHECK(hipStreamDestroy(s_dl));
+  });
+  factorize_async();
+  const int r = wait();
+  stop.store(true, std::memory_order_release);
+  helper.join();
+  if (r == 0)
+    fetch_column(nt - 1, s_high);
+  return r;
 }
 
 // =============================================================================== single-tile ops

@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstddef>
 #include <cstdint>
 #include <memory>
@@ -138,6 +139,11 @@ struct DeviceMatrix : MatrixBase {
   // with A - L L^H on the uplo triangle; returns max|A - L L^H| and max|A| over the whole grid.
   void residual_of(DeviceMatrix<T>& factor, double* max_diff, double* max_a);
   int factorize();                         // blocking; returns LAPACK-style info
+  // factorize() of a matrix that upload() just filled from `host`, with the download of every finished
+  // tile column overlapped with the rest of the factorization (a helper thread follows ev_panel[k]); on
+  // return `host` holds the factor.  The blocking host entry points (dlaf_p?potrf ...) use it.
+  int factorize_and_download(T* host, long ld);
+  std::atomic<long> panels_issued{-1};     // last step whose ev_panel has been recorded by factorize_async
   void factorize_async();                  // enqueue only
   int wait();                              // drain + info
 };
