@@ -504,7 +504,15 @@ static void potrf_tile(T* t, int ld, int kb, T* winv, int* info, int info_base, 
 // explicit order, because on this GPU a high-priority stream's kernels do not pre-empt the queued
 // workgroups of a running bulk kernel.
 //
-// "early diagonal" schedule (process grids; DLAF_MI355X_SCHEDULE=early|classic overrides): with
+// "sidecar" schedule (one process, real types, nb <= 768, where a step's bulk is short and the serial TRSM
+// and the split of the bulk into two launches cost most): POTRF(k) AND TRSM(k) ride on s_panel beside the
+// WHOLE bulk update of step k-1, one persistent launch that leaves 32 workgroup slots free; the lookahead
+// column follows both:
+//
+//   s_main : U(k-1, rest) ................. U(k, col k+1) . U(k, rest) ...
+//   s_panel: POTRF(k) . TRSM(k)                              POTRF(k+1) . TRSM(k+1)
+//
+// "early diagonal" schedule (process grids; DLAF_MI355X_SCHEDULE=early|classic|sidecar overrides): with
 // broadcasts in the loop the per-step chain POTRF -> bcast -> TRSM -> bcast -> U(col k+1) -> POTRF is
 // what bounds a multi-GPU run, so the diagonal tile leaves that chain.  The lookahead is two columns
 // deep, the panel's first tile ("head": A(k+1,k), the only operand D(k+1) needs) is solved and
@@ -530,6 +538,21 @@ void DeviceMatrix<T>::factorize_async() {
     if (const char* e = std::getenv("DLAF_MI355X_SCHEDULE"))
       return std::strcmp(e, "early") == 0;
     return dist;
+  }();
+  // one process only: POTRF(k) and TRSM(k) both ride on the panel stream beside the WHOLE bulk update of
+  // step k-1 (one persistent launch that leaves `sidecar_slots` workgroup slots free)
+  // Measured (one MI355X, fp64): nb=512 N=32768 48.6 -> 52.5 TFlop/s, nb=256 N=16384 27.6 -> 30.1, nb=768
+  // 47.6 -> 51.0; at nb=1024 the classic order with its tuned lookahead slice is 2 % faster, and for complex
+  // types (one TRSM workgroup per compute unit) it is 3 % faster at every size tried.
+  const bool sidecar = [&] {
+    if (const char* e = std::getenv("DLAF_MI355X_SCHEDULE"))
+      return std::strcmp(e, "sidecar") == 0 && !dist;
+    return !dist && !TypeInfo<T>::is_complex && nb <= 768;
+  }();
+  const long sidecar_slots = [&]() -> long {
+    if (const char* e = std::getenv("DLAF_MI355X_SIDECAR_SLOTS"))
+      return std::atol(e);
+    return 32;
   }();
 
   for (auto& ps : prof) {
@@ -621,7 +644,9 @@ void DeviceMatrix<T>::factorize_async() {
   };
 
   // panel TRSM of local tile rows [il0, il1) of local tile column klc with the factored diagonal tile
-  auto trsm = [&](long il0, long il1, long klc, const T* Lkk, const T* Wkk, int kb) {
+  auto trsm = [&](long il0, long il1, long klc, const T* Lkk, const T* Wkk, int kb, hipStream_t ts = nullptr) {
+    if (ts == nullptr)
+      ts = s_main;
     if (il0 >= il1)
       return;
     TrsmArgs<T> ta;
@@ -647,9 +672,9 @@ void DeviceMatrix<T>::factorize_async() {
       fl += (TypeInfo<T>::is_complex ? 4.0 : 1.0) * (double) kb * kb * mi;
       by += (0.5 * kb * kb + 2.0 * mi * kb) * sizeof(T);
     }
-    prof_begin(2, s_main);
-    launch_trsm(ta, s_main);
-    prof_end(2, s_main, fl, by);
+    prof_begin(2, ts);
+    launch_trsm(ta, ts);
+    prof_end(2, ts, fl, by);
   };
 
   // diagonal tile k on its owner (s_panel); the inverted diagonal blocks alternate between two buffers
@@ -731,7 +756,44 @@ void DeviceMatrix<T>::factorize_async() {
 
   Step prev;  // step k-1, whose bulk update is still to be issued (in part or in full)
 
-  if (early) {
+  if (sidecar) {
+    for (long k = 0; k < nt; ++k) {
+      const int kb = rows.tile_extent(k);
+      const long il_n = rows.next_local(k + 1), jl_n = cols.next_local(k + 1);
+      const long klc = cols.local_of(k);
+      if (k >= 1)
+        DLAF_HIP_CHECK(hipStreamWaitEvent(s_panel, ev_high[k - 1], 0));
+      potrf(k);
+      if (k == nt - 1) {
+        update(prev, prev.rest0, ltc, s_main, 0, sidecar_slots);
+        DLAF_HIP_CHECK(hipEventRecord(ev_diag[k], s_panel));
+        DLAF_HIP_CHECK(hipStreamWaitEvent(s_main, ev_diag[k], 0));
+        break;
+      }
+      trsm(il_n, ltr, klc, tile(rows.local_of(k), klc), winv_of(k), kb, s_panel);
+      DLAF_HIP_CHECK(hipEventRecord(ev_panel[k], s_panel));
+      panels_issued.store(k, std::memory_order_release);
+      // the whole bulk of step k-1 beside them
+      update(prev, prev.rest0, ltc, s_main, 0, sidecar_slots);
+      DLAF_HIP_CHECK(hipStreamWaitEvent(s_main, ev_panel[k], 0));
+      Step cur;
+      cur.valid = true;
+      cur.kb = kb;
+      cur.il_n = il_n;
+      cur.jl_n = jl_n;
+      cur.a_base = tile(il_n < ltr ? il_n : 0, klc);
+      cur.b_base = cur.a_base + (cols.global_of(jl_n) - il_n) * (long) tile_elems;
+      cur.b_ts = (long) tile_elems * cols.P;
+      cur.rest0 = jl_n;
+      if (jl_n < ltc) {
+        update(cur, jl_n, jl_n + 1, s_main, 1, 0);
+        cur.rest0 = jl_n + 1;
+      }
+      DLAF_HIP_CHECK(hipEventRecord(ev_high[k], s_main));
+      prev = cur;
+    }
+  }
+  else if (early) {
     potrf(0);
     for (long k = 0; k < nt; ++k) {
       const int kb = rows.tile_extent(k);
