@@ -85,7 +85,7 @@ def main():
         ok &= grid.selftest(3 << 14) == 0   # row / column communicator wiring through the Transport interface
         cases = [("d", "L", 150, 32), ("d", "U", 150, 32), ("z", "L", 100, 16), ("z", "U", 70, 16),
                  ("s", "L", 96, 32), ("c", "U", 64, 16), ("d", "L", 34, 13), ("d", "L", 5, 8), ("d", "U", 260, 64),
-                 ("d", "L", 530, 32), ("z", "U", 300, 16)]
+                 ("d", "L", 530, 32), ("z", "U", 300, 16), ("d", "U", 1100, 128), ("z", "L", 700, 128)]
         for t, uplo, n, nb in cases:
             dt = oracle.DTYPES[t]
             sr, sc = max(0, nprow - 1), min(1, npcol - 1)  # test_cholesky.cpp:85: non-zero source rank
