@@ -207,3 +207,14 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    """bench.py measures the HIP path only: on a box without a GPU it must say so and exit non-zero, never fall
+    back to a CPU computation."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], cwd=ROOT, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "needs a GPU" in (r.stderr + r.stdout) and '"metric"' not in r.stdout
