@@ -242,6 +242,17 @@ class DeviceMatrix:
         assert a.dtype == self.dtype
         lib().dlaf_mi355x_matrix_download(self._h, _ptr(a), _ld_of(a))
 
+    def fetch_tile(self, gi: int, gj: int):
+        """Global tile (gi, gj) of the device copy as a dense column-major array, or None when this process
+        does not own it (a checker samples a large factor tile by tile instead of downloading it whole)."""
+        rows = min(self.nb, self.n - gi * self.nb)
+        cols = min(self.nb, self.n - gj * self.nb)
+        out = np.zeros((rows, cols), dtype=self.dtype, order="F")
+        r = lib().dlaf_mi355x_matrix_fetch_tile(self._h, gi, gj, _ptr(out), max(1, rows))
+        if r < 0:
+            raise ValueError(f"dlaf_mi355x_matrix_fetch_tile failed with {r}")
+        return out if r == 0 else None
+
     def copy_from(self, other: "DeviceMatrix") -> None:
         r = lib().dlaf_mi355x_matrix_copy(self._h, other._h)
         if r != 0:

@@ -28,9 +28,15 @@ namespace {
 // grid registry: contexts count down from INT_MAX (reference: src/c_api/grid.cpp:26-31)
 std::unordered_map<int, std::unique_ptr<Grid>> g_grids;
 
+// A context is never handed out twice while its grid is alive: the reference numbers them
+// INT_MAX - size() (grid.cpp:31) and relies on try_emplace never replacing a live entry; here the
+// search simply continues downwards past contexts that are still registered (create A, create B,
+// free A, create C must not give C the context of B).
 int register_grid(std::unique_ptr<Grid> g) {
-  const int ctx = INT_MAX - (int) g_grids.size();
-  g_grids[ctx] = std::move(g);
+  int ctx = INT_MAX - (int) g_grids.size();
+  while (g_grids.find(ctx) != g_grids.end())
+    --ctx;
+  g_grids.emplace(ctx, std::move(g));
   return ctx;
 }
 
@@ -311,6 +317,15 @@ int dlaf_mi355x_create_grid_host(int nranks, int rank, int nprow, int npcol, cha
   return register_grid(std::move(g));
 }
 
+int dlaf_mi355x_grid_on_free(int ctx, void (*fn)(void*), void* user) noexcept {
+  auto it = g_grids.find(ctx);
+  if (it == g_grids.end())
+    return -1;
+  it->second->on_free = fn;
+  it->second->on_free_user = user;
+  return 0;
+}
+
 int dlaf_mi355x_grid_info(int ctx, int* nprow, int* npcol, int* myrow, int* mycol) noexcept {
   auto it = g_grids.find(ctx);
   if (it == g_grids.end())
@@ -443,6 +458,9 @@ int dlaf_mi355x_matrix_copy(dlaf_mi355x_matrix_t dst, dlaf_mi355x_matrix_t src) 
   if (!src || !dst || src->type != dst->type)
     return -1;
   WITH_MATRIX(dst, M.copy_from(static_cast<DeviceMatrix<DT>&>(*src->m)); return 0;)
+}
+int dlaf_mi355x_matrix_fetch_tile(dlaf_mi355x_matrix_t h, long gi, long gj, void* host, int ld) noexcept {
+  WITH_MATRIX(h, return M.fetch_tile(gi, gj, static_cast<DT*>(host), ld) ? 0 : 1;)
 }
 int dlaf_mi355x_cholesky_start(dlaf_mi355x_matrix_t h) noexcept {
   WITH_MATRIX(h, M.factorize_async(); return 0;)

@@ -45,6 +45,22 @@ int host_bcast(void* user, int axis, int root, void* buf, size_t bytes) {
 int host_barrier(void* user) {
   return MPI_Barrier(static_cast<MpiComms*>(user)->world) == MPI_SUCCESS ? 0 : 1;
 }
+
+// dlaf_free_grid / dlaf_finalize of the core library end here: drop this grid's communicators
+void release_comms(void* user) {
+  auto* c = static_cast<MpiComms*>(user);
+  int finalized = 0;
+  MPI_Finalized(&finalized);
+  for (auto it = g_comms.begin(); it != g_comms.end(); ++it)
+    if (it->second.get() == c) {
+      if (!finalized)
+        for (MPI_Comm* m : {&c->world, &c->row, &c->col})
+          if (*m != MPI_COMM_NULL)
+            MPI_Comm_free(m);
+      g_comms.erase(it);
+      return;
+    }
+}
 }  // namespace
 
 extern "C" int dlaf_create_grid(MPI_Comm comm, int nprow, int npcol, char order) noexcept {
@@ -71,7 +87,8 @@ extern "C" int dlaf_create_grid(MPI_Comm comm, int nprow, int npcol, char order)
     MPI_Comm_split(comm, myrow, mycol, &c->row);
     MPI_Comm_split(comm, mycol, myrow, &c->col);
     const int ctx = dlaf_mi355x_create_grid_host(size, rank, nprow, npcol, order, host_bcast, host_barrier, c.get());
-    g_comms[ctx] = std::move(c);
+    dlaf_mi355x_grid_on_free(ctx, release_comms, c.get());
+    g_comms.emplace(ctx, std::move(c));  // contexts are unique among live grids: never replaces an entry
     return ctx;
   }
   char uid[DLAF_MI355X_UNIQUE_ID_BYTES];

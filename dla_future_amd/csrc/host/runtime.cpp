@@ -1146,6 +1146,16 @@ int DeviceMatrix<T>::wait() {
   DLAF_HIP_CHECK(hipStreamSynchronize(s_low));
   DLAF_HIP_CHECK(hipStreamSynchronize(s_high));
   DLAF_HIP_CHECK(hipMemcpy(info_host, info, sizeof(int), hipMemcpyDeviceToHost));
+  if (grid->nranks > 1 && grid->transport) {
+      // one value for the whole grid (ScaLAPACK's p?potrf contract; the reference aborts every rank,
+    // src/cusolver/assert_info.cu:35-45): v[0] carries the LAPACK index, v[1] the scheduling failure
+    // (the SMALLEST positive index wins: ranks that did not see the failing tile keep computing on the
+    // garbage it broadcast and may flag a later pivot of their own; MAX of 2^31 - info = MIN of info)
+    constexpr double kTop = 2147483648.0;
+    double v[2] = {*info_host > 0 ? kTop - (double) *info_host : 0.0, *info_host == kInfoSchedulingFailure ? 1.0 : 0.0};
+    grid->transport->allreduce_max(v, 2, grid->nprow, grid->npcol, grid->myrow, grid->mycol);
+    *info_host = v[1] > 0 ? kInfoSchedulingFailure : (v[0] > 0 ? (int) (kTop - v[0]) : 0);
+  }
   if (*info_host == kInfoSchedulingFailure)
     fatal("[dlaf_mi355x] cooperative POTRF: a bounded inter-workgroup wait expired (workgroups not co-resident); "
           "the result is invalid. DLAF_MI355X_POTRF=chain selects the non-cooperative path.\n");
@@ -1159,6 +1169,31 @@ int DeviceMatrix<T>::wait() {
     }
   }
   return *info_host;
+}
+
+template <class T>
+bool DeviceMatrix<T>::fetch_tile(long gi, long gj, T* host, long ld) {
+  // view indices: the device holds the transposed view for uplo == 'U'
+  const long vi = transposed ? gj : gi, vj = transposed ? gi : gj;
+  if (vi < 0 || vj < 0 || vi >= nt || vj >= nt || !rows.mine(vi) || !cols.mine(vj))
+    return false;
+  const int r = rows.tile_extent(vi), c = cols.tile_extent(vj);
+  const T* src = tile(rows.local_of(vi), cols.local_of(vj));
+  DLAF_HIP_CHECK(hipStreamSynchronize(s_low));
+  DLAF_HIP_CHECK(hipStreamSynchronize(s_high));
+  if (!transposed) {
+    DLAF_HIP_CHECK(hipMemcpy2D(host, (size_t) ld * sizeof(T), src, (size_t) nb * sizeof(T), (size_t) r * sizeof(T),
+                               (size_t) c, hipMemcpyDeviceToHost));
+  }
+  else {
+    T* tmp = dev_alloc<T>(tile_elems);
+    launch_copy2d(tmp, (long) c, src, (long) nb, c, r, 1, 0, s_high);  // caller's tile is c x r
+    DLAF_HIP_CHECK(hipStreamSynchronize(s_high));
+    DLAF_HIP_CHECK(hipMemcpy2D(host, (size_t) ld * sizeof(T), tmp, (size_t) c * sizeof(T), (size_t) c * sizeof(T),
+                               (size_t) r, hipMemcpyDeviceToHost));
+    DLAF_HIP_CHECK(hipFree(tmp));
+  }
+  return true;
 }
 
 template <class T>

@@ -65,6 +65,15 @@ struct Grid {
   dlaf_host_bcast_fn host_bcast = nullptr;
   dlaf_host_barrier_fn host_barrier = nullptr;
   void* host_user = nullptr;
+  // called once when the grid is freed (dlaf_free_grid / dlaf_finalize): releases what the creator of a
+  // host grid keeps alive for the callbacks (the MPI shim's communicators)
+  void (*on_free)(void*) = nullptr;
+  void* on_free_user = nullptr;
+  ~Grid() {
+    transport.reset();
+    if (on_free)
+      on_free(on_free_user);
+  }
 };
 
 std::unique_ptr<Transport> make_rccl_transport(const void* unique_id, int nranks, int rank, int nprow,
@@ -145,7 +154,13 @@ struct DeviceMatrix : MatrixBase {
   int factorize_and_download(T* host, long ld);
   std::atomic<long> panels_issued{-1};     // last step whose ev_panel has been recorded by factorize_async
   void factorize_async();                  // enqueue only
-  int wait();                              // drain + info
+  // drain + info.  On a process grid the LAPACK info is made the same on every rank (MAX over the grid of
+  // the device flags: every kernel that saw the failing diagonal tile stored the same index, the others 0;
+  // the scheduling-failure code wins over everything) -- collective, like the factorization itself.
+  int wait();
+  // one tile of the device copy (global tile indices of the caller's matrix, not of the transposed view)
+  // to / from a dense host array; returns false when this rank does not own the tile
+  bool fetch_tile(long gi, long gj, T* host, long ld);
 };
 
 // single-tile operations with host operands (tests of the tile kernels through the C ABI)

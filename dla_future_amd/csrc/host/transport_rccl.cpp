@@ -34,9 +34,15 @@ public:
     DLAF_NCCL_CHECK(ncclCommSplit(world_, mycol, myrow, &col_, nullptr));
     DLAF_HIP_CHECK(hipMalloc(&token_, sizeof(int)));
     DLAF_HIP_CHECK(hipMemset(token_, 0, sizeof(int)));
+    DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&scal_dev_), sizeof(double) * kScalars));
+    DLAF_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&scal_host_), sizeof(double) * kScalars, hipHostMallocDefault));
+    DLAF_HIP_CHECK(hipStreamCreateWithFlags(&scal_stream_, hipStreamNonBlocking));
   }
   ~RcclTransport() override {
     (void) hipFree(token_);
+    (void) hipFree(scal_dev_);
+    (void) hipHostFree(scal_host_);
+    (void) hipStreamDestroy(scal_stream_);
     if (row_)
       (void) ncclCommDestroy(row_);
     if (col_)
@@ -59,18 +65,25 @@ public:
     DLAF_HIP_CHECK(hipStreamSynchronize(stream));
   }
   void allreduce_max(double* host_vals, int n, int, int, int, int) override {
-    double* d = nullptr;
-    DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d), sizeof(double) * n));
-    DLAF_HIP_CHECK(hipMemcpy(d, host_vals, sizeof(double) * n, hipMemcpyHostToDevice));
-    DLAF_NCCL_CHECK(ncclAllReduce(d, d, n, ncclDouble, ncclMax, world_, nullptr));
-    DLAF_HIP_CHECK(hipStreamSynchronize(nullptr));
-    DLAF_HIP_CHECK(hipMemcpy(host_vals, d, sizeof(double) * n, hipMemcpyDeviceToHost));
-    DLAF_HIP_CHECK(hipFree(d));
+    // a handful of scalars (norms, info): a persistent device word buffer + pinned mirror on a stream of
+    // their own -- no allocation, no null-stream synchronisation (every factorization ends with one)
+    if (n > kScalars)
+      fatal("[dlaf_mi355x] allreduce_max of %d values (max %d)\n", n, kScalars);
+    std::memcpy(scal_host_, host_vals, sizeof(double) * (size_t) n);
+    DLAF_HIP_CHECK(hipMemcpyAsync(scal_dev_, scal_host_, sizeof(double) * (size_t) n, hipMemcpyHostToDevice, scal_stream_));
+    DLAF_NCCL_CHECK(ncclAllReduce(scal_dev_, scal_dev_, (size_t) n, ncclDouble, ncclMax, world_, scal_stream_));
+    DLAF_HIP_CHECK(hipMemcpyAsync(scal_host_, scal_dev_, sizeof(double) * (size_t) n, hipMemcpyDeviceToHost, scal_stream_));
+    DLAF_HIP_CHECK(hipStreamSynchronize(scal_stream_));
+    std::memcpy(host_vals, scal_host_, sizeof(double) * (size_t) n);
   }
 
 private:
+  static constexpr int kScalars = 16;
   ncclComm_t world_ = nullptr, row_ = nullptr, col_ = nullptr;
   void* token_ = nullptr;
+  double* scal_dev_ = nullptr;
+  double* scal_host_ = nullptr;
+  hipStream_t scal_stream_ = nullptr;
 };
 }  // namespace
 

@@ -44,6 +44,10 @@ DLAF_EXTERN_C int dlaf_mi355x_create_grid_host(int nranks, int rank, int nprow, 
  * the row (axis 0) / column (axis 1) communicators of a host grid for CPU-only tests. */
 DLAF_EXTERN_C int dlaf_mi355x_grid_host_bcast(int context, int axis, int root, void* host_buf, size_t bytes) DLAF_NOEXCEPT;
 
+/* fn(user) is called once when the grid is freed (dlaf_free_grid / dlaf_finalize): the creator of a host
+ * grid releases there what its callbacks use (the MPI shim frees its communicators).  -1: unknown context. */
+DLAF_EXTERN_C int dlaf_mi355x_grid_on_free(int context, void (*fn)(void*), void* user) DLAF_NOEXCEPT;
+
 /* my coordinates in a grid; returns 0, or -1 for an unknown context */
 DLAF_EXTERN_C int dlaf_mi355x_grid_info(int context, int* nprow, int* npcol, int* myrow, int* mycol) DLAF_NOEXCEPT;
 
@@ -58,6 +62,11 @@ DLAF_EXTERN_C void dlaf_mi355x_matrix_destroy(dlaf_mi355x_matrix_t m) DLAF_NOEXC
 DLAF_EXTERN_C int dlaf_mi355x_matrix_upload(dlaf_mi355x_matrix_t m, const void* host_local, int ld) DLAF_NOEXCEPT;
 DLAF_EXTERN_C int dlaf_mi355x_matrix_download(dlaf_mi355x_matrix_t m, void* host_local, int ld) DLAF_NOEXCEPT;
 DLAF_EXTERN_C int dlaf_mi355x_matrix_copy(dlaf_mi355x_matrix_t dst, dlaf_mi355x_matrix_t src) DLAF_NOEXCEPT;
+/* one global tile (gi, gj) of the device copy into a dense host array (column-major, ld >= tile rows), as the
+ * caller's matrix stores it.  Returns 0, 1 when this process does not own the tile, < 0 on a bad handle.
+ * Lets a checker sample an N = 65536 factor without moving 32 GiB. */
+DLAF_EXTERN_C int dlaf_mi355x_matrix_fetch_tile(dlaf_mi355x_matrix_t m, long gi, long gj, void* host,
+                                                int ld) DLAF_NOEXCEPT;
 /* enqueue the factorization / wait for it (returns info) / both */
 DLAF_EXTERN_C int dlaf_mi355x_cholesky_start(dlaf_mi355x_matrix_t m) DLAF_NOEXCEPT;
 DLAF_EXTERN_C int dlaf_mi355x_cholesky_wait(dlaf_mi355x_matrix_t m) DLAF_NOEXCEPT;

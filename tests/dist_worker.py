@@ -110,6 +110,27 @@ def main():
                     print(f"[dist_worker] FAILED case {t}{uplo} n={n} nb={nb} grid {nprow}x{npcol}: max diff {md}", flush=True)
                 ok &= good
             ok &= bool((store[rows:, :] == 7.5).all())
+        # not positive definite: every rank must report the SAME LAPACK info (the reference aborts every rank,
+        # src/cusolver/assert_info.cu:35-45, lapack/tile.h:374-378); nobody hangs, nobody returns 0
+        for t, uplo, n, nb, bad in [("d", "L", 400, 64, 300), ("d", "U", 400, 64, 300), ("z", "L", 200, 32, 77),
+                                    ("d", "L", 400, 128, 0)]:
+            dt = oracle.DTYPES[t]
+            sr, sc = max(0, nprow - 1), min(1, npcol - 1)
+            a0 = oracle.set_random_hpd(n, nb, dt)
+            a0[bad, bad] = -1.0
+            loc = np.asfortranarray(oracle.scatter(a0, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
+            info = dlaf.cholesky_factorization(grid, uplo, loc, nb, sr, sc, n=n)
+            infos = [None] * dist.get_world_size()
+            dist.all_gather_object(infos, int(info))
+            good = all(i == bad + 1 for i in infos)
+            if not good and rank == 0:
+                print(f"[dist_worker] non-SPD {t}{uplo} n={n} nb={nb}: infos {infos}, expected {bad + 1} everywhere", flush=True)
+            ok &= good
+            # device-resident entry: same contract
+            m = dlaf.DeviceMatrix(grid, dt, uplo, n, nb, sr, sc)
+            m.upload(np.asfortranarray(oracle.scatter(a0, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)]))
+            ok &= m.factorize() == bad + 1
+            m.close()
         # device-side residual checker with the MAX reduction over the grid (miniapp check_cholesky)
         for t, uplo, n, nb in [("d", "L", 200, 32), ("z", "U", 90, 16)]:
             dt = oracle.DTYPES[t]

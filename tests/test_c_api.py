@@ -54,8 +54,11 @@ def test_mpi_grid_entry_points_cpu(nprow, npcol, order):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nprow,npcol,order", [(1, 1, "R"), (1, 2, "R"), (2, 2, "C"), (3, 2, "R")])
+@pytest.mark.parametrize("nprow,npcol,order", [(1, 1, "R"), (1, 2, "R"), (2, 2, "C"),
+                                               pytest.param(3, 2, "R", marks=pytest.mark.many_ranks)])
 def test_pdpotrf_pzpotrf_from_c_with_mpi(nprow, npcol, order):
+    from conftest import gpu_process_budget
+    gpu_process_budget(nprow * npcol)
     exe = build("test_pdpotrf")
     r = run(exe, nprow, npcol, order, 600)
     assert r.returncode == 0 and "C_API_TEST OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

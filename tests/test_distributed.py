@@ -24,20 +24,13 @@ def free_port():
     return p
 
 
-def gpu_open_in_this_process():
-    capi = sys.modules.get("dla_future_amd.capi")
-    torch = sys.modules.get("torch")
-    return (capi is not None and getattr(capi, "_lib", None) is not None) or \
-        (torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized())
-
-
 def launch(mode, nprow, npcol, order, timeout, extra_env=None):
     """Start one worker process per rank directly (no launcher process: the GPU box allows at most 6
     processes on the card, and 3x2 / 2x3 grids need all of them)."""
     n = nprow * npcol
-    if mode == "gpu" and n >= 6 and gpu_open_in_this_process():
-        pytest.skip("this pytest process already holds the GPU (GPU tests ran before): 6 ranks + 1 exceed the "
-                    "box's limit of 6 processes on the card; run this file first or on its own")
+    if mode == "gpu":
+        from conftest import gpu_process_budget
+        gpu_process_budget(n)
     port = str(free_port())
     procs = []
     for rank in range(n):
@@ -65,8 +58,12 @@ def test_grid_wiring_and_generation_gloo_cpu(nprow, npcol, order):
     launch("cpu", nprow, npcol, order, timeout=300)
 
 
+SIX = pytest.mark.many_ranks
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("nprow,npcol,order", [(1, 2, "R"), (2, 1, "R"), (2, 2, "C"), (3, 2, "R"), (2, 3, "C")])
+@pytest.mark.parametrize("nprow,npcol,order", [(1, 2, "R"), (2, 1, "R"), (2, 2, "C"),
+                                               pytest.param(3, 2, "R", marks=SIX), pytest.param(2, 3, "C", marks=SIX)])
 def test_distributed_cholesky_one_gpu_many_ranks(nprow, npcol, order):
     launch("gpu", nprow, npcol, order, timeout=600)
 

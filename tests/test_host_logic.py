@@ -136,6 +136,29 @@ def test_contexts_count_down_from_int_max(dlaf):
     b.free()
 
 
+def test_a_live_grid_never_loses_its_context(dlaf):
+    """create A, create B, free A, create C: C must not be handed B's context (the reference numbers contexts
+    INT_MAX - #grids, src/c_api/grid.cpp:31, and never replaces a live entry); B keeps its shape, and freeing
+    C leaves B alive."""
+    lib = dlaf.lib()
+    a = dlaf.Grid.single()
+    b = dlaf.Grid.host(1, 0, 1, 1, "C", lambda *args: None)
+    a.free()
+    c = dlaf.Grid.single()
+    assert c.context != b.context
+    r = [C.c_int(-1) for _ in range(4)]
+    assert lib.dlaf_mi355x_grid_info(b.context, *(C.byref(x) for x in r)) == 0
+    assert [x.value for x in r] == [1, 1, 0, 0]
+    freed = []
+    cb = C.CFUNCTYPE(None, C.c_void_p)(lambda u: freed.append(u))
+    assert lib.dlaf_mi355x_grid_on_free(c.context, C.cast(cb, C.c_void_p), 1234) == 0
+    c.free()
+    assert freed == [1234]
+    assert lib.dlaf_mi355x_grid_info(b.context, *(C.byref(x) for x in r)) == 0
+    assert lib.dlaf_mi355x_grid_info(c.context if c.context >= 0 else 5, *(C.byref(x) for x in r)) == -1
+    b.free()
+
+
 def _run(code):
     return subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=120)
 
