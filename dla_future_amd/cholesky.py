@@ -119,6 +119,18 @@ class Grid:
         """Collective wiring check of the row / column communicators; number of failed checks (0 = good)."""
         return int(lib().dlaf_mi355x_grid_selftest(self.context, nbytes))
 
+    def comm_log(self, enable: bool = True) -> None:
+        """Start (and clear) / stop the communication log of this grid (dlaf_mi355x_grid_comm_log)."""
+        lib().dlaf_mi355x_grid_comm_log(self.context, 1 if enable else 0)
+
+    def comm_log_events(self):
+        """[(kind, root, bytes, grouped), ...] recorded since comm_log(True): kind 0 row broadcast, 1 column
+        broadcast, 2 step marker (root = step), 3 barrier, 4 all-reduce."""
+        n = lib().dlaf_mi355x_grid_comm_log_read(self.context, None, 0)
+        buf = (C.c_long * (4 * max(1, n)))()
+        lib().dlaf_mi355x_grid_comm_log_read(self.context, buf, n)
+        return [tuple(buf[4 * i:4 * i + 4]) for i in range(n)]
+
     def free(self) -> None:
         """dlaf_free_grid (include/dlaf_c/grid.h:39)."""
         if self.context >= 0:

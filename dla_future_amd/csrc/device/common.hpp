@@ -110,7 +110,7 @@ __device__ __forceinline__ int acc_as_operand_k(int g, int v) {
   return Mma<R>::irow(g, v);
 }
 
-constexpr int kThreads = 256;  // 4 waves per workgroup everywhere
+constexpr int kThreads = 256;  // 4 waves per workgroup (the default; BlockCfg::THREADS says otherwise where it differs)
 constexpr int kLdsPad = 16;    // elements of padding per k-row of an LDS panel image:
                                // (ROWS+16)*8 B = 128 mod 256 and (ROWS+16)*4 B = 64 mod 128,
                                // so the 4 k-rows a wave reads per MFMA step hit disjoint banks
@@ -120,16 +120,16 @@ constexpr int kLdsPad = 16;    // elements of padding per k-row of an LDS panel 
 // (k-major, rows contiguous), one plane for real types, re/im planes for complex.
 // VEC: 16-byte loads (needs src 16-B aligned, ld*sizeof(T) % 16 == 0); otherwise per element.
 // IL (complex only): re/im interleaved in LDS ([k][LD] of (re, im) pairs) instead of two planes.
-template <class T, int ROWS, int BK, bool VEC, int LD_ = ROWS + kLdsPad, bool IL = false>
+template <class T, int ROWS, int BK, bool VEC, int LD_ = ROWS + kLdsPad, bool IL = false, int THREADS = kThreads>
 struct Slab {
   using R = real_t<T>;
   static constexpr bool CX = TypeInfo<T>::is_complex;
   static constexpr int VE = VEC ? ((16 / (int) sizeof(T)) > 0 ? (16 / (int) sizeof(T)) : 1) : 1;
-  static constexpr int NL = (ROWS * BK) / (kThreads * VE);
+  static constexpr int NL = (ROWS * BK) / (THREADS * VE);
   static constexpr int LD = LD_;
   static constexpr int PLANE = BK * LD;                  // elements of R per plane
   static constexpr int ELEMS = (CX ? 2 : 1) * PLANE;     // elements of R per slab image
-  static_assert((ROWS * BK) % (kThreads * VE) == 0, "slab must divide over the workgroup");
+  static_assert((ROWS * BK) % (THREADS * VE) == 0, "slab must divide over the workgroup");
   static_assert(ROWS % VE == 0, "rows must be a multiple of the vector width");
 
   T regs[NL][VE];
@@ -140,7 +140,7 @@ struct Slab {
     const int t = threadIdx.x;
 #pragma unroll
     for (int q = 0; q < NL; ++q) {
-      const int idx = t + kThreads * q;
+      const int idx = t + THREADS * q;
       const int r = (idx % (ROWS / VE)) * VE;
       const int k = idx / (ROWS / VE);
       const T* p = src + r + (long) (k0 + k) * ld;
@@ -168,7 +168,7 @@ struct Slab {
     const int t = threadIdx.x;
 #pragma unroll
     for (int q = 0; q < NL; ++q) {
-      const int idx = t + kThreads * q;
+      const int idx = t + THREADS * q;
       const int r = (idx % (ROWS / VE)) * VE;
       const int k = idx / (ROWS / VE);
       if constexpr (IL) {

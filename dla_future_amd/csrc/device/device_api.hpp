@@ -43,6 +43,11 @@ struct UpdateArgs {
   // own tile count / last extent (the triangular solver updates an m x n right-hand side, solver.cpp)
   int rect = 0;
   int nt_c = 0, last_cols = 0;
+  // b_period > 1: the transposed panel is stored grouped by the process row that sent it (one broadcast
+  // per root instead of one per tile): B(jl) = b + ((jl-jl0) % b_period) * b_ts2 + ((jl-jl0) / b_period) * b_ts
+  int b_period = 1;
+  long b_ts2 = 0;
+  int b_jl0 = -1;  // local tile column that b stands for (-1: jl0)
 };
 // role: 0 trailing bulk, 1 lookahead column, 2 in-tile POTRF update / single-tile entries, 3 residual checker
 // and triangular solver (same code, separate kernel names, so that profiles of the factorization stay clean)

@@ -28,8 +28,15 @@ template <>
 struct UpdateCfg<double> {
   // 2 stages x BK 16 and 4 stages x BK 8 measure the same (67.5 TFlop/s standalone): the in-loop
   // global traffic costs clock (DVFS), not latency -- see DESIGN.md
+#if defined(DLAF_UPD_BIG)
+  // 256 x 128 block, 8 waves (4 x 2 wave tiles of 64 x 64), one workgroup per compute unit: 25 % fewer
+  // L2 -> LDS bytes per flop than two independent 128 x 128 blocks
+  using type = BlockCfg<double, 256, 128, 64, 64, 16, true, DLAF_UPD_BIG, 512>;
+  static constexpr int min_waves = 2;
+#else
   using type = BlockCfg<double, 128, 128, 64, 64, 16, true, 2>;
   static constexpr int min_waves = 2;
+#endif
 };
 template <>
 struct UpdateCfg<cfloat> {
@@ -112,7 +119,9 @@ __device__ __forceinline__ void update_block(const UpdateArgs<T>& p, const Updat
   const T* A = p.a + (long) (il - p.il0) * p.a_ts + m0;
   // herk on a diagonal tile reads the COLUMN panel for both operands (impl.h:282-287): the
   // transposed panel never holds the tile of the last global row (broadcast_panel.h:186-191)
-  const T* B = diag ? p.a + (long) (il - p.il0) * p.a_ts + n0 : p.b + (long) (jl - p.jl0) * p.b_ts + n0;
+  const int jt = jl - (p.b_jl0 >= 0 ? p.b_jl0 : p.jl0);
+  const T* B = diag ? p.a + (long) (il - p.il0) * p.a_ts + n0
+                    : p.b + (long) (jt % p.b_period) * p.b_ts2 + (long) (jt / p.b_period) * p.b_ts + n0;
   const long ldb = diag ? p.lda : p.ldb;
 #ifdef DLAF_DBG_SAME_STRIPS
   A = p.a;  // tuning aid (tools/update_bench.hip): every block streams the same two strips = perfect L2 locality
@@ -259,7 +268,8 @@ __device__ __forceinline__ void update_block(const UpdateArgs<T>& p, const Updat
 // leaves the compute units the launcher did not ask for free for the resident POTRF / RCCL kernels
 // that must run beside the bulk update and (b) keeps each XCD on neighbouring patches.
 template <class T, bool VEC, int ROLE>
-__global__ __launch_bounds__(kThreads, UpdateCfg<T>::min_waves) void update_kernel(UpdateArgs<T> p, UpdateMap mp) {
+__global__ __launch_bounds__(UpdateCfg<T>::type::THREADS, UpdateCfg<T>::min_waves) void update_kernel(UpdateArgs<T> p,
+                                                                                                     UpdateMap mp) {
   using R = real_t<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   R* lds = reinterpret_cast<R*>(lds_raw);
@@ -353,11 +363,11 @@ void launch_update(const UpdateArgs<T>& a, hipStream_t stream, int role, long ma
     (void) hipMemsetAsync(counters, 0, 8 * sizeof(unsigned), stream);
   }
   const bool vec = aligned16<T>(a.a, a.lda) && aligned16<T>(a.a, a.a_ts) && aligned16<T>(a.b, a.ldb) &&
-                   aligned16<T>(a.b, a.b_ts);
+                   aligned16<T>(a.b, a.b_ts) && aligned16<T>(a.b, a.b_ts2);
   auto go = [&](auto vtag, auto rtag) {
     constexpr bool V = decltype(vtag)::value;
     constexpr int RL = decltype(rtag)::value;
-    hipLaunchKernelGGL((update_kernel<T, V, RL>), dim3((unsigned) grid), dim3(kThreads), Cfg::LDS_BYTES, stream, a, mp);
+    hipLaunchKernelGGL((update_kernel<T, V, RL>), dim3((unsigned) grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, a, mp);
   };
   auto by_role = [&](auto vtag) {
     switch (role) {
@@ -378,7 +388,7 @@ template <class T>
 int update_blocks_per_cu() {
   using Cfg = typename UpdateCfg<T>::type;
   int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&update_kernel<T, true, 0>), kThreads,
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&update_kernel<T, true, 0>), Cfg::THREADS,
                                                    Cfg::LDS_BYTES) != hipSuccess || n < 1)
     n = 1;
   return n;

@@ -15,14 +15,16 @@ namespace dlaf_mi355x {
 // STAGES_: LDS slab buffers.  2 = classic double buffering; the direct-to-LDS path uses more so that
 // STAGES-1 slabs are in flight (counted s_waitcnt vmcnt + raw s_barrier) and HBM/L2 latency spikes
 // do not stall the MFMA stream.
-template <class T, int BM_, int BN_, int WM_, int WN_, int BK_, bool PAIRED_ = false, int STAGES_ = 2>
+template <class T, int BM_, int BN_, int WM_, int WN_, int BK_, bool PAIRED_ = false, int STAGES_ = 2,
+          int THREADS_ = kThreads>
 struct BlockCfg {
   using R = real_t<T>;
   static constexpr bool CX = TypeInfo<T>::is_complex;
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = BK_;
+  static constexpr int THREADS = THREADS_, NWAVES = THREADS_ / 64;
   static constexpr int TM = WM / 16, TN = WN / 16;
   static constexpr int WAVES_M = BM / WM, WAVES_N = BN / WN;
-  static_assert(WAVES_M * WAVES_N * 64 == kThreads, "4 waves per workgroup");
+  static_assert(WAVES_M * WAVES_N == NWAVES, "the wave tiles must cover the block");
   static_assert(BK % 4 == 0 && WM % 16 == 0 && WN % 16 == 0, "MFMA 16x16x4 granularity");
   // For complex types PAIRED_ selects the interleaved LDS image instead ([k][ROWS] of (re, im)): one
   // ds_read_b128 per fragment and, with 64-row granularity, direct-to-LDS staging of 16-byte elements.
@@ -31,14 +33,16 @@ struct BlockCfg {
   static_assert(!PAIRED || (TM % 2 == 0 && TN % 2 == 0), "paired rows: even tile counts");
   static constexpr int PAD = PAIRED_ ? 0 : kLdsPad;
   static constexpr int LDA = BM + PAD, LDB = BN + PAD;
-  // direct-to-LDS staging: one wave instruction (64 lanes x 16 B = 1 KiB, contiguous in LDS) moves CPI whole
-  // slab columns of the unpadded image (1 for 128 fp64 rows, 2 for 64 fp64 rows, ...); every wave issues the
-  // same number of them per slab
-  static constexpr int CPI_A = CX ? 1 : 1024 / ((int) sizeof(T) * BM), CPI_B = CX ? 1 : 1024 / ((int) sizeof(T) * BN);
+  // direct-to-LDS staging: one wave instruction (64 lanes x 16 B = 1 KiB, contiguous in LDS) moves one PIECE
+  // of the unpadded image [k][ROWS]: EPP consecutive elements = a run of whole columns (ROWS <= EPP) or a
+  // part of one column (ROWS > EPP); every wave issues the same number of them per slab
+  static constexpr int EPP = CX ? 64 : 1024 / (int) sizeof(T);
+  static constexpr int PIECES_A = BK * BM / EPP, PIECES_B = BK * BN / EPP;
   static constexpr bool GLDS =
-      (PAIRED && CPI_A >= 1 && CPI_B >= 1 && CPI_A * (int) sizeof(T) * BM == 1024 &&
-       CPI_B * (int) sizeof(T) * BN == 1024 && BK % (4 * CPI_A) == 0 && BK % (4 * CPI_B) == 0) ||
-      (CXI && sizeof(T) == 16 && BM % 64 == 0 && BN % 64 == 0);
+      (PAIRED && (EPP % BM == 0 || BM % EPP == 0) && (EPP % BN == 0 || BN % EPP == 0) && (BK * BM) % EPP == 0 &&
+       (BK * BN) % EPP == 0 && PIECES_A % NWAVES == 0 && PIECES_B % NWAVES == 0) ||
+      (CXI && sizeof(T) == 16 && BM % 64 == 0 && BN % 64 == 0 && PIECES_A % NWAVES == 0 && PIECES_B % NWAVES == 0);
+  static constexpr int LPS = PIECES_A / NWAVES + PIECES_B / NWAVES;  // direct-to-LDS loads per wave and slab
   static constexpr int A_PLANE = BK * LDA, B_PLANE = BK * LDB;
   static constexpr int A_ELEMS = (CX ? 2 : 1) * A_PLANE, B_ELEMS = (CX ? 2 : 1) * B_PLANE;
   static constexpr int BUF_ELEMS = A_ELEMS + B_ELEMS;
@@ -155,17 +159,18 @@ __device__ __forceinline__ int acc_n(int j, int g, int v) {
     return j * 16 + Mma<R>::irow(g, v);
 }
 
-// Direct-to-LDS staging of one BK slab of A and B (Cfg::GLDS): wave w moves columns
-// [w*BK/4, (w+1)*BK/4) of both panels, one global_load_lds_dwordx4 (1 KiB = one column) each.
+// Direct-to-LDS staging of one BK slab of A and B (Cfg::GLDS): the image of each panel is cut into 1 KiB
+// pieces (one global_load_lds_dwordx4 each), wave w moves a contiguous run of them.
 template <class Cfg, class T>
 __device__ __forceinline__ void stage_glds(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb, int k0,
                                            typename Cfg::R* __restrict__ buf, int wave, int lane) {
+  constexpr int NA = Cfg::PIECES_A / Cfg::NWAVES, NB = Cfg::PIECES_B / Cfg::NWAVES;  // instructions per wave
   if constexpr (Cfg::CXI) {
-    // 16-byte elements: one instruction moves 64 rows of one column; wave w takes every 4th piece
+    // 16-byte elements: one instruction moves 64 rows of one column; wave w takes every NWAVES-th piece
     constexpr int PA = Cfg::BM / 64, PB = Cfg::BN / 64;
 #pragma unroll
-    for (int idx = 0; idx < (Cfg::BK * PA) / 4; ++idx) {
-      const int piece = wave + 4 * idx;
+    for (int idx = 0; idx < NA; ++idx) {
+      const int piece = wave + Cfg::NWAVES * idx;
       const int k = piece / PA, part = piece % PA;
       const T* ga = A + part * 64 + lane + (long) (k0 + k) * lda;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) ga,
@@ -173,8 +178,8 @@ __device__ __forceinline__ void stage_glds(const T* __restrict__ A, long lda, co
                                        16, 0, 0);
     }
 #pragma unroll
-    for (int idx = 0; idx < (Cfg::BK * PB) / 4; ++idx) {
-      const int piece = wave + 4 * idx;
+    for (int idx = 0; idx < NB; ++idx) {
+      const int piece = wave + Cfg::NWAVES * idx;
       const int k = piece / PB, part = piece % PB;
       const T* gb = B + part * 64 + lane + (long) (k0 + k) * ldb;
       __builtin_amdgcn_global_load_lds(
@@ -184,23 +189,22 @@ __device__ __forceinline__ void stage_glds(const T* __restrict__ A, long lda, co
     return;
   }
   constexpr int PER = 16 / (int) sizeof(T);  // elements per lane
-  // one instruction = CPI consecutive columns: lane -> (column lane / LPC, rows (lane % LPC) * PER ...)
-  constexpr int LPC_A = 64 / Cfg::CPI_A, LPC_B = 64 / Cfg::CPI_B;
-  constexpr int NA = Cfg::BK / Cfg::CPI_A / 4, NB = Cfg::BK / Cfg::CPI_B / 4;  // instructions per wave
+  constexpr int EPP = Cfg::EPP;              // elements per piece
 #pragma unroll
   for (int q = 0; q < NA; ++q) {
-    const int k = (wave * NA + q) * Cfg::CPI_A;
-    const T* ga = A + (lane % LPC_A) * PER + (long) (k0 + k + lane / LPC_A) * lda;
+    const int e0 = (wave * NA + q) * EPP;    // first element of the piece in the image [k][BM]
+    const int e = e0 + lane * PER;
+    const T* ga = A + (e % Cfg::BM) + (long) (k0 + e / Cfg::BM) * lda;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) ga,
-                                     (__attribute__((address_space(3))) void*) (buf + k * Cfg::LDA), 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*) (buf + e0), 16, 0, 0);
   }
 #pragma unroll
   for (int q = 0; q < NB; ++q) {
-    const int k = (wave * NB + q) * Cfg::CPI_B;
-    const T* gb = B + (lane % LPC_B) * PER + (long) (k0 + k + lane / LPC_B) * ldb;
+    const int e0 = (wave * NB + q) * EPP;
+    const int e = e0 + lane * PER;
+    const T* gb = B + (e % Cfg::BN) + (long) (k0 + e / Cfg::BN) * ldb;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) gb,
-                                     (__attribute__((address_space(3))) void*) (buf + Cfg::A_ELEMS + k * Cfg::LDB), 16,
-                                     0, 0);
+                                     (__attribute__((address_space(3))) void*) (buf + Cfg::A_ELEMS + e0), 16, 0, 0);
   }
 }
 
@@ -223,8 +227,8 @@ __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda,
     // consumed.  Each wave issues LPS loads per slab; "vmcnt(LPS*(STAGES-2))" therefore means "my share
     // of slab kt+1 has landed", and the raw barrier extends that to every wave's share.
     constexpr int ST = Cfg::STAGES;
-    constexpr int LPS = Cfg::CXI ? (Cfg::BK * (Cfg::BM / 64) + Cfg::BK * (Cfg::BN / 64)) / 4
-                                 : Cfg::BK / Cfg::CPI_A / 4 + Cfg::BK / Cfg::CPI_B / 4;
+    constexpr int LPS = Cfg::LPS;
+    static_assert(LPS * (ST - 2) < 64, "vmcnt is a 6-bit counter");
 #pragma unroll
     for (int s = 0; s < ST - 1; ++s)
       if (s < nk)
@@ -258,8 +262,8 @@ __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda,
     }
     return;
   }
-  Slab<T, Cfg::BM, Cfg::BK, VEC, Cfg::LDA, Cfg::CXI> sa;
-  Slab<T, Cfg::BN, Cfg::BK, VEC, Cfg::LDB, Cfg::CXI> sb;
+  Slab<T, Cfg::BM, Cfg::BK, VEC, Cfg::LDA, Cfg::CXI, Cfg::THREADS> sa;
+  Slab<T, Cfg::BN, Cfg::BK, VEC, Cfg::LDB, Cfg::CXI, Cfg::THREADS> sb;
   sa.template load<EDGE>(A, lda, 0, mrows, K);
   sb.template load<EDGE>(B, ldb, 0, ncols, K);
   sa.store(lds);

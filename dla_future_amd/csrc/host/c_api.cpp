@@ -326,6 +326,32 @@ int dlaf_mi355x_grid_on_free(int ctx, void (*fn)(void*), void* user) noexcept {
   return 0;
 }
 
+int dlaf_mi355x_grid_comm_log(int ctx, int enable) noexcept {
+  auto it = g_grids.find(ctx);
+  if (it == g_grids.end())
+    return -1;
+  Grid& g = *it->second;
+  g.comm_log_on = enable != 0;
+  g.comm_log.clear();
+  if (g.comm_log_on && runtime_initialized())
+    (void) grid_transport(g);
+  return 0;
+}
+
+long dlaf_mi355x_grid_comm_log_read(int ctx, long* out, long cap_events) noexcept {
+  auto it = g_grids.find(ctx);
+  if (it == g_grids.end())
+    return -1;
+  const auto& log = it->second->comm_log;
+  for (long i = 0; out && i < cap_events && i < (long) log.size(); ++i) {
+    out[4 * i + 0] = log[(size_t) i].kind;
+    out[4 * i + 1] = log[(size_t) i].root;
+    out[4 * i + 2] = log[(size_t) i].bytes;
+    out[4 * i + 3] = log[(size_t) i].group;
+  }
+  return (long) log.size();
+}
+
 int dlaf_mi355x_grid_info(int ctx, int* nprow, int* npcol, int* myrow, int* mycol) noexcept {
   auto it = g_grids.find(ctx);
   if (it == g_grids.end())

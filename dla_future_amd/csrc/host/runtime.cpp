@@ -120,6 +120,52 @@ std::unique_ptr<Transport> make_host_transport(dlaf_host_bcast_fn b, dlaf_host_b
   return std::unique_ptr<Transport>(new HostTransport(b, bar, user));
 }
 
+// =============================================================================== recording wrapper
+namespace {
+class RecordingTransport final : public Transport {
+public:
+  RecordingTransport(std::unique_ptr<Transport> inner, Grid* g) : inner_(std::move(inner)), g_(g) {}
+  bool device_side() const override { return inner_->device_side(); }
+  void bcast(CommAxis axis, int root, int my_index, const void* send, void* recv, size_t bytes,
+             hipStream_t stream) override {
+    if (bytes != 0)
+      g_->comm_log.push_back({(long) axis, (long) root, (long) bytes, (long) depth_});
+    inner_->bcast(axis, root, my_index, send, recv, bytes, stream);
+  }
+  void group_begin() override {
+    ++depth_;
+    inner_->group_begin();
+  }
+  void group_end() override {
+    --depth_;
+    inner_->group_end();
+  }
+  void barrier(hipStream_t stream) override {
+    g_->comm_log.push_back({3, 0, 0, 0});
+    inner_->barrier(stream);
+  }
+  void allreduce_max(double* v, int n, int nprow, int npcol, int myrow, int mycol) override {
+    g_->comm_log.push_back({4, 0, (long) (n * sizeof(double)), 0});
+    inner_->allreduce_max(v, n, nprow, npcol, myrow, mycol);
+  }
+  void mark(long step) override { g_->comm_log.push_back({2, step, 0, 0}); }
+  bool is_recorder() const { return true; }
+
+private:
+  std::unique_ptr<Transport> inner_;
+  Grid* g_;
+  int depth_ = 0;
+};
+}  // namespace
+
+Transport* grid_transport(Grid& g) {
+  if (g.nranks > 1 && !g.transport && g.host_bcast)
+    g.transport = make_host_transport(g.host_bcast, g.host_barrier, g.host_user);
+  if (g.transport && g.comm_log_on && dynamic_cast<RecordingTransport*>(g.transport.get()) == nullptr)
+    g.transport = std::unique_ptr<Transport>(new RecordingTransport(std::move(g.transport), &g));
+  return g.transport.get();
+}
+
 // =============================================================================== DeviceMatrix
 template <class T>
 static T* dev_alloc(size_t elems) {
@@ -142,8 +188,7 @@ void DeviceMatrix<T>::create(Grid* g, char uplo_, long n_, int nb_, int isrc, in
   runtime_init();
   type = TypeInfo<T>::tag;
   grid = g;
-  if (g->nranks > 1 && !g->transport && g->host_bcast)
-    g->transport = make_host_transport(g->host_bcast, g->host_barrier, g->host_user);
+  (void) grid_transport(*g);
   uplo = (uplo_ == 'U' || uplo_ == 'u') ? 'U' : 'L';
   transposed = (uplo == 'U');
   n = n_;
@@ -164,7 +209,8 @@ void DeviceMatrix<T>::create(Grid* g, char uplo_, long n_, int nb_, int isrc, in
     diag_ws = dev_alloc<T>(2 * (tile_elems + winv_elems()));  // alternating by step parity
     for (int b = 0; b < 2; ++b) {
       panel[b] = dev_alloc<T>((size_t) ltr * tile_elems);
-      panelT[b] = dev_alloc<T>((size_t) ltc * tile_elems);
+      // grouped by root process row: up to rows.P classes of ceil(ltc / classes) tiles each
+      panelT[b] = dev_alloc<T>((size_t) (ltc + rows.P) * tile_elems);
     }
   }
   {
@@ -488,6 +534,51 @@ static void potrf_tile(T* t, int ld, int kb, T* winv, int* info, int info_base, 
   }
 }
 
+// ------------------------------------------------------------------------------- transposed panel
+static long gcd_l(long a, long b) {
+  while (b) {
+    const long t = a % b;
+    a = b;
+    b = t;
+  }
+  return a;
+}
+
+template <class T>
+int DeviceMatrix<T>::bcast_transposed_panel(Transport* tr, CommAxis ax_col, const T* a_base, long il_n, long jl_n,
+                                            T* dst, hipStream_t s, int& period, long& ts2) {
+  const size_t tile_bytes = tile_elems * sizeof(T);
+  const long ncols = ltc - jl_n;
+  // owner(global_of(jl)) repeats in jl with period lcm(Pr, Pc) / Pc = Pr / gcd(Pr, Pc)
+  const long g = gcd_l(rows.P, cols.P);
+  period = (int) (rows.P / g);
+  const long lstep = cols.P / g;  // local-row distance on the root between consecutive tiles of a class
+  const long cap = ncols > 0 ? (ncols + period - 1) / period : 0;
+  ts2 = cap * (long) tile_elems;
+  int issued = 0;
+  tr->group_begin();
+  for (long c = 0; c < period && c < ncols; ++c) {
+    const long jl_first = jl_n + c;
+    const long gj_first = cols.global_of(jl_first);
+    const int root_r = rows.owner(gj_first);
+    long cnt = (ncols - c + period - 1) / period;
+    if (cols.global_of(jl_first + (cnt - 1) * period) == nt - 1)
+      --cnt;
+    if (cnt <= 0)
+      continue;
+    T* d = dst + c * ts2;
+    if (rows.rank == root_r) {
+      const T* src = a_base + (size_t) (rows.local_of(gj_first) - il_n) * tile_elems;
+      DLAF_HIP_CHECK(hipMemcpy2DAsync(d, tile_bytes, src, (size_t) lstep * tile_bytes, tile_bytes, (size_t) cnt,
+                                      hipMemcpyDeviceToDevice, s));
+    }
+    tr->bcast(ax_col, root_r, rows.rank, d, d, (size_t) cnt * tile_bytes, s);
+    ++issued;
+  }
+  tr->group_end();
+  return issued;
+}
+
 // ------------------------------------------------------------------------------- the tile DAG
 // Right-looking Cholesky (cholesky/impl.h:150-189 local, :192-313 distributed) of the lower
 // triangle of the view.  Three in-order streams; events carry the RAW/WAR edges the reference gets
@@ -524,7 +615,7 @@ static void potrf_tile(T* t, int ld, int kb, T* winv, int* info, int info_base, 
 //   s_panel:             herk D(k+1) -= head head^H . POTRF(k+1)
 template <class T>
 void DeviceMatrix<T>::factorize_async() {
-  Transport* tr = grid->transport.get();
+  Transport* tr = grid_transport(*grid);
   const bool dist = grid->nranks > 1;
   if (dist && !tr)
     fatal("[dlaf_mi355x] grid with %d ranks has no transport\n", grid->nranks);
@@ -593,6 +684,8 @@ void DeviceMatrix<T>::factorize_async() {
     const T* a_base = nullptr;  // column panel: tile of local row il at a_base + (il - il_n)*tile_elems
     const T* b_base = nullptr;  // transposed panel: tile of local col jl at b_base + (jl - jl_n)*b_ts
     long b_ts = 0, il_n = 0, jl_n = 0;
+    int b_period = 1;  // transposed panel grouped by root process row: see bcast_transposed_panel
+    long b_ts2 = 0;
     int kb = 0;
     long rest0 = 0, split = 0;  // classic: rest_A = [rest0, split), rest_B = [split, ltc); early: rest = [rest0, ltc)
     bool valid = false;
@@ -618,8 +711,11 @@ void DeviceMatrix<T>::factorize_async() {
     ua.a = st.a_base + (size_t) (il0 - st.il_n) * tile_elems;
     ua.a_ts = (long) tile_elems;
     ua.lda = nb;
-    ua.b = st.b_base + (j0 - st.jl_n) * st.b_ts;
+    ua.b = st.b_base;
     ua.b_ts = st.b_ts;
+    ua.b_period = st.b_period;
+    ua.b_ts2 = st.b_ts2;
+    ua.b_jl0 = (int) st.jl_n;
     ua.ldb = nb;
     ua.il0 = (int) il0;
     ua.il1 = (int) il1;
@@ -721,17 +817,9 @@ void DeviceMatrix<T>::factorize_async() {
   // column panel that plays its role when this process holds every row
   auto transposed_panel = [&](long k, Step& cur, int buf) {
     if (rows.P > 1) {
-      tr->group_begin();
-      for (long jl = cur.jl_n; jl < ltc; ++jl) {
-        const long gj = cols.global_of(jl);
-        if (gj == nt - 1)
-          continue;  // last tile row is only ever a herk operand (broadcast_panel.h:186-191)
-        const int root_r = rows.owner(gj);
-        const T* src = (rows.rank == root_r) ? cur.a_base + (size_t) (rows.local_of(gj) - cur.il_n) * tile_elems : nullptr;
-        tr->bcast(ax_col, root_r, rows.rank, src, panelT[buf] + (size_t) (jl - cur.jl_n) * tile_elems, tile_bytes, s_comm);
-      }
-      tr->group_end();
+      bcast_transposed_panel(tr, ax_col, cur.a_base, cur.il_n, cur.jl_n, panelT[buf], s_comm, cur.b_period, cur.b_ts2);
       cur.b_base = panelT[buf];
+      cur.b_ts = (long) tile_elems;
     }
     else {
       // I hold every row of the panel: tile gj sits at local row gj
@@ -759,6 +847,8 @@ void DeviceMatrix<T>::factorize_async() {
   if (sidecar) {
     for (long k = 0; k < nt; ++k) {
       const int kb = rows.tile_extent(k);
+      if (tr)
+        tr->mark(k);
       const long il_n = rows.next_local(k + 1), jl_n = cols.next_local(k + 1);
       const long klc = cols.local_of(k);
       if (k >= 1)
@@ -797,6 +887,8 @@ void DeviceMatrix<T>::factorize_async() {
     potrf(0);
     for (long k = 0; k < nt; ++k) {
       const int kb = rows.tile_extent(k);
+      if (tr)
+        tr->mark(k);
       const int own_c = cols.owner(k);
       const bool in_row = rows.rank == rows.owner(k), in_col = cols.rank == own_c;
       const long il_n = rows.next_local(k + 1), jl_n = cols.next_local(k + 1);
@@ -885,6 +977,8 @@ void DeviceMatrix<T>::factorize_async() {
     }();
     for (long k = 0; k < nt; ++k) {
       const int kb = rows.tile_extent(k);
+      if (tr)
+        tr->mark(k);
       const int own_c = cols.owner(k);
       const bool in_row = rows.rank == rows.owner(k), in_col = cols.rank == own_c;
       const long il_n = rows.next_local(k + 1), jl_n = cols.next_local(k + 1);
@@ -973,9 +1067,7 @@ void DeviceMatrix<T>::factorize_async() {
 // ------------------------------------------------------------------------------- grid self-test
 int grid_selftest(Grid& g, size_t bytes) {
   runtime_init();
-  if (g.nranks > 1 && !g.transport && g.host_bcast)
-    g.transport = make_host_transport(g.host_bcast, g.host_barrier, g.host_user);
-  Transport* tr = g.transport.get();
+  Transport* tr = grid_transport(g);
   if (!tr)
     return 0;  // 1x1 grid without communicators
   const size_t words = std::max<size_t>(1, bytes / sizeof(unsigned));
@@ -1043,7 +1135,7 @@ template <class T>
 void DeviceMatrix<T>::residual_of(DeviceMatrix<T>& L, double* max_diff, double* max_a) {
   if (L.n != n || L.nb != nb || L.ltr != ltr || L.ltc != ltc || L.transposed != transposed)
     fatal("[dlaf_mi355x] residual_of: matrices differ in shape or distribution\n");
-  Transport* tr = grid->transport.get();
+  Transport* tr = grid_transport(*grid);
   const bool dist = grid->nranks > 1;
   const CommAxis ax_row = transposed ? CommAxis::Col : CommAxis::Row;
   const CommAxis ax_col = transposed ? CommAxis::Row : CommAxis::Col;
@@ -1076,17 +1168,10 @@ void DeviceMatrix<T>::residual_of(DeviceMatrix<T>& L, double* max_diff, double* 
     else {
       a_base = L.tile(il_f < ltr ? il_f : 0, klc);
     }
+    int b_period = 1;
+    long b_ts2 = 0;
     if (rows.P > 1) {
-      tr->group_begin();
-      for (long jl = jl_f; jl < ltc; ++jl) {
-        const long gj = cols.global_of(jl);
-        if (gj == nt - 1 && gj != k)
-          continue;
-        const int root_r = rows.owner(gj);
-        const T* src = (rows.rank == root_r) ? a_base + (size_t) (rows.local_of(gj) - il_f) * tile_elems : nullptr;
-        tr->bcast(ax_col, root_r, rows.rank, src, panelT[0] + (size_t) (jl - jl_f) * tile_elems, tile_bytes, s);
-      }
-      tr->group_end();
+      bcast_transposed_panel(tr, ax_col, a_base, il_f, jl_f, panelT[0], s, b_period, b_ts2);
       b_base = panelT[0];
     }
     else {
@@ -1108,6 +1193,9 @@ void DeviceMatrix<T>::residual_of(DeviceMatrix<T>& L, double* max_diff, double* 
     ua.lda = nb;
     ua.b = b_base;
     ua.b_ts = b_ts;
+    ua.b_period = b_period;
+    ua.b_ts2 = b_ts2;
+    ua.b_jl0 = (int) jl_f;
     ua.ldb = nb;
     ua.il0 = (int) il0;
     ua.il1 = (int) ltr;

@@ -54,6 +54,18 @@ public:
   // max over every rank of the grid of n host doubles (the reference's sync::reduce with MPI_MAX in
   // max_norm, include/dlaf/auxiliary/norm/mc.h); result on every rank
   virtual void allreduce_max(double* host_vals, int n, int nprow, int npcol, int myrow, int mycol) = 0;
+  // step marker of the executor (a no-op for real transports; the recording wrapper logs it)
+  virtual void mark(long /*step*/) {}
+};
+
+// One communication event as the recording transport logs it (dlaf_mi355x_grid_comm_log_*): what the
+// reference's CommunicatorPipeline token serialises (sender/transform_mpi.h:60-75) -- every member of a
+// communicator must issue the same sequence.
+struct CommEvent {
+  long kind;   // 0 row broadcast, 1 column broadcast, 2 step marker, 3 barrier, 4 allreduce
+  long root;   // broadcast: root index inside the communicator; marker: step
+  long bytes;
+  long group;  // 1: issued inside group_begin / group_end
 };
 
 struct Grid {
@@ -69,6 +81,9 @@ struct Grid {
   // host grid keeps alive for the callbacks (the MPI shim's communicators)
   void (*on_free)(void*) = nullptr;
   void* on_free_user = nullptr;
+  // communication log (tests): when on, `transport` is wrapped by a recorder that appends here
+  bool comm_log_on = false;
+  std::vector<CommEvent> comm_log;
   ~Grid() {
     transport.reset();
     if (on_free)
@@ -79,6 +94,9 @@ struct Grid {
 std::unique_ptr<Transport> make_rccl_transport(const void* unique_id, int nranks, int rank, int nprow,
                                                int npcol, int myrow, int mycol);
 void rccl_get_unique_id(void* out128);
+// creates the lazily-built host transport of a grid and, when the grid's communication log is on, wraps the
+// transport with the recorder; idempotent.  Returns the transport (null for a 1x1 grid without communicators).
+Transport* grid_transport(Grid& g);
 std::unique_ptr<Transport> make_host_transport(dlaf_host_bcast_fn bcast, dlaf_host_barrier_fn barrier,
                                                void* user);
 
@@ -131,6 +149,15 @@ struct DeviceMatrix : MatrixBase {
   bool profiling = true;
   void prof_begin(int kind, hipStream_t s);
   void prof_end(int kind, hipStream_t s, double flops, double bytes);
+
+  // Transposed panel of a step down the process columns (communication/broadcast_panel.h:125-210), ONE
+  // broadcast per root process row: the local tile columns jl >= jl_n fall into `period` classes by the
+  // process row that owns global tile row global_of(jl); class c = tiles jl_n + c, jl_n + c + period, ...
+  // lands contiguously at dst + c * ts2 (the root packs its -- strided -- tiles there first).  a_base: column
+  // panel, tile of local row il at a_base + (il - il_n) * tile_elems.  The tile of the last global row is
+  // never a gemm operand and stays out (:186-191).  Returns the number of broadcasts issued.
+  int bcast_transposed_panel(Transport* tr, CommAxis ax_col, const T* a_base, long il_n, long jl_n, T* dst,
+                             hipStream_t s, int& period, long& ts2);
 
   T* tile(long il, long jl) const { return tiles + (size_t) (il + jl * ltr) * tile_elems; }
   size_t winv_elems() const { return (size_t) ((nb + kDiagBlock - 1) / kDiagBlock) * kDiagBlock * kDiagBlock; }

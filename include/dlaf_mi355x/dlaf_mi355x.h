@@ -48,6 +48,17 @@ DLAF_EXTERN_C int dlaf_mi355x_grid_host_bcast(int context, int axis, int root, v
  * grid releases there what its callbacks use (the MPI shim frees its communicators).  -1: unknown context. */
 DLAF_EXTERN_C int dlaf_mi355x_grid_on_free(int context, void (*fn)(void*), void* user) DLAF_NOEXCEPT;
 
+/* Communication log of a grid (test instrument): while enabled, every broadcast / barrier / all-reduce the
+ * library issues on this grid and a marker per factorization step are appended to a per-process list of
+ * events {kind, root, bytes, grouped}: kind 0 row broadcast, 1 column broadcast (root = index inside that
+ * communicator), 2 step marker (root = step), 3 barrier, 4 all-reduce.  Every member of a communicator must
+ * log the same sequence for it -- the property the reference's communicator pipeline enforces
+ * (sender/transform_mpi.h:60-75).  enable != 0 clears the list and starts recording.  _read copies up to
+ * cap_events events (4 longs each) and returns the number recorded. */
+DLAF_EXTERN_C int dlaf_mi355x_grid_comm_log(int context, int enable) DLAF_NOEXCEPT;
+DLAF_EXTERN_C long dlaf_mi355x_grid_comm_log_read(int context, long* out_4_longs_per_event,
+                                                  long cap_events) DLAF_NOEXCEPT;
+
 /* my coordinates in a grid; returns 0, or -1 for an unknown context */
 DLAF_EXTERN_C int dlaf_mi355x_grid_info(int context, int* nprow, int* npcol, int* myrow, int* mycol) DLAF_NOEXCEPT;
 

@@ -110,6 +110,57 @@ def main():
                     print(f"[dist_worker] FAILED case {t}{uplo} n={n} nb={nb} grid {nprow}x{npcol}: max diff {md}", flush=True)
                 ok &= good
             ok &= bool((store[rows:, :] == 7.5).all())
+        # Communication pattern (recording transport): every member of a row / column communicator logs the SAME
+        # sequence of broadcasts for it -- the reference's communicator-pipeline property
+        # (sender/transform_mpi.h:60-75) -- under both issue orders a grid can run, and the transposed panel
+        # costs at most one column broadcast per root process row and step (not one per tile).
+        sched0 = os.environ.get("DLAF_MI355X_SCHEDULE")
+        for sched in ("early", "classic"):
+            os.environ["DLAF_MI355X_SCHEDULE"] = sched
+            for uplo, n, nb in (("L", 700, 64), ("U", 530, 32)):
+                sr, sc = max(0, nprow - 1), min(1, npcol - 1)
+                rows, cols = grid.local_shape(n, nb, sr, sc)
+                loc = np.zeros((max(1, rows), max(1, cols)), order="F")[:rows, :cols]
+                dlaf.set_random_hermitian_positive_definite(grid, loc, n, nb, sr, sc)
+                grid.comm_log(True)
+                info = dlaf.cholesky_factorization(grid, uplo, loc, nb, sr, sc, n=n)
+                ev = grid.comm_log_events()
+                grid.comm_log(False)
+                ok &= info == 0
+                allev = [None] * dist.get_world_size()
+                dist.all_gather_object(allev, (grid.myrow, grid.mycol, ev))
+                if rank == 0:
+                    by = {(r, c): e for r, c, e in allev}
+                    good = True
+                    for kind, same in ((0, lambda a, b: a[0] == b[0]), (1, lambda a, b: a[1] == b[1])):
+                        for a in by:
+                            for b in by:
+                                if a < b and same(a, b):
+                                    sa = [e for e in by[a] if e[0] == kind]
+                                    sb = [e for e in by[b] if e[0] == kind]
+                                    good &= sa == sb and len(sa) > 0 or (len(sa) == 0 and len(sb) == 0 and
+                                                                          (npcol if kind == 0 else nprow) == 1)
+                    # per step and rank: column-axis broadcasts of the caller's grid (for uplo U the view's process
+                    # rows are the caller's process columns, so the grouped transposed panel travels on axis 0)
+                    t_axis, t_roots = (1, nprow) if uplo == "L" else (0, npcol)
+                    worst = 0
+                    for e_list in by.values():
+                        cur = 0
+                        for e in e_list:
+                            if e[0] == 2:
+                                worst, cur = max(worst, cur), 0
+                            elif e[0] == t_axis and e[3] == 1:   # grouped = transposed panel
+                                cur += 1
+                        worst = max(worst, cur)
+                    good &= worst <= t_roots
+                    nt_ = (n + nb - 1) // nb
+                    if not good:
+                        print(f"[dist_worker] comm pattern FAILED sched={sched} uplo={uplo}: worst grouped bcasts/step "
+                              f"{worst} (limit {t_roots}), nt={nt_}", flush=True)
+                    ok &= bool(good)
+        os.environ.pop("DLAF_MI355X_SCHEDULE", None)
+        if sched0 is not None:
+            os.environ["DLAF_MI355X_SCHEDULE"] = sched0
         # not positive definite: every rank must report the SAME LAPACK info (the reference aborts every rank,
         # src/cusolver/assert_info.cu:35-45, lapack/tile.h:374-378); nobody hangs, nobody returns 0
         for t, uplo, n, nb, bad in [("d", "L", 400, 64, 300), ("d", "U", 400, 64, 300), ("z", "L", 200, 32, 77),

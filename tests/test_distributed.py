@@ -112,3 +112,26 @@ def test_rccl_communicators_on_a_one_process_grid():
     r = subprocess.run([sys.executable, "-c", RCCL_SINGLE % ROOT], cwd=ROOT, env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and "RCCL_SINGLE OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_bench_line_on_a_four_rank_grid_with_the_host_transport():
+    """bench.py --gpus 4 as the driver launches it (torch.distributed.run, one rank per process), with the
+    host-staged transport so that the four ranks can share this box's one GPU: exercises the N > 1 JSON line
+    (grid, transport, MAX-reduced time, device-side residual over the grid)."""
+    import json
+    from conftest import gpu_process_budget
+    gpu_process_budget(4)
+    env = dict(os.environ, OMP_NUM_THREADS="1", DLAF_MI355X_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
+           "--matrix-size", "4096", "--block-size", "256", "--transport", "host", "--check", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 4 and line["config"]["grid"] == "2x2" and line["config"]["transport"] == "host"
+    assert line["steps"] == 2 and line["value"] > 0 and line["unit"] == "TFlop/s"
+    assert line["residual"]["ok"], line["residual"]
+    assert "roofline" in line and "cpu_baseline" not in line   # the CPU baseline is an N = 1 item

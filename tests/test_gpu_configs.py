@@ -55,7 +55,7 @@ def test_C0_miniapp_cholesky_n4096_nb256(dlaf):
     from test_cpp_api import build_miniapp, check_miniapp_output
     exe = build_miniapp()
     r = subprocess.run([exe, "--matrix-size", "4096", "--block-size", "256", "--type", "d", "--nruns", "2", "--nwarmups", "1",
-                        "--check-result", "last"], cwd=ROOT, capture_output=True, text=True, timeout=600,
+                        "--check-result", "last", "--csv"], cwd=ROOT, capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, DLAF_MI355X_DEVICE="0"))
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     check_miniapp_output(r.stdout, 2, 1)
