@@ -10,17 +10,18 @@ Python doorway onto that ABI, mirroring the reference's operator surface for the
     dlaf_p{s,d,c,z}potrf                               include/dlaf_c/factorization/cholesky.h:74-87
     dlaf::cholesky_factorization(uplo, Matrix&)        include/dlaf/factorization/cholesky.h:39-79
     dlaf::triangular_solver(side, uplo, op, diag, ...)  include/dlaf/solver/triangular.h:41-177 (next row, SURVEY 8(f)2)
+    generalized_to_standard(grid, uplo, A, B)          include/dlaf/eigensolver/gen_to_std.h:50,:101
 
 There is no CPU fallback: importing works anywhere, every compute call needs the HIP library
 and a GPU and fails loudly otherwise.
 """
 from .capi import (DLAFDescriptor, LibraryNotBuilt, lib, lib_path, type_char, version)  # noqa: F401
-from .cholesky import (DeviceMatrix, Grid, cholesky_factorization, finalize, initialize, make_descriptor,  # noqa: F401
-                       pxpotrf, pxpotrs, pxtrsm, set_random_hermitian_positive_definite, tile_gemm, tile_herk, tile_potrf,
+from .cholesky import (DeviceMatrix, Grid, cholesky_factorization, finalize, generalized_to_standard,  # noqa: F401
+                       initialize, make_descriptor, pxhegst, pxpotrf, pxpotrs, pxtrsm, set_random_hermitian_positive_definite, tile_gemm, tile_herk, tile_potrf,
                        tile_trsm, triangular_solver, solver_profile)
 from . import distribution  # noqa: F401
 
 __all__ = ["DLAFDescriptor", "DeviceMatrix", "Grid", "LibraryNotBuilt", "cholesky_factorization", "distribution",
-           "finalize", "initialize", "lib", "lib_path", "make_descriptor", "pxpotrf", "pxpotrs", "pxtrsm",
+           "finalize", "generalized_to_standard", "initialize", "lib", "lib_path", "make_descriptor", "pxhegst", "pxpotrf", "pxpotrs", "pxtrsm",
            "set_random_hermitian_positive_definite", "solver_profile", "tile_gemm", "tile_herk", "tile_potrf", "tile_trsm",
            "triangular_solver", "type_char", "version"]

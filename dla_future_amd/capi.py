@@ -95,6 +95,15 @@ SIGNATURES = {
     "dlaf_mi355x_pcpotrs": (None, [_ch, _i, _i, _vp, _i, _i, _IP, _vp, _i, _i, _IP, _IP]),
     "dlaf_mi355x_pzpotrs": (None, [_ch, _i, _i, _vp, _i, _i, _IP, _vp, _i, _i, _IP, _IP]),
     "dlaf_mi355x_solver_profile": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "dlaf_mi355x_generalized_to_standard_s": (_i, [_i, _ch, _vp, DLAFDescriptor, _vp, DLAFDescriptor]),
+    "dlaf_mi355x_generalized_to_standard_d": (_i, [_i, _ch, _vp, DLAFDescriptor, _vp, DLAFDescriptor]),
+    "dlaf_mi355x_generalized_to_standard_c": (_i, [_i, _ch, _vp, DLAFDescriptor, _vp, DLAFDescriptor]),
+    "dlaf_mi355x_generalized_to_standard_z": (_i, [_i, _ch, _vp, DLAFDescriptor, _vp, DLAFDescriptor]),
+    "dlaf_mi355x_pshegst": (None, [_i, _ch, _i, _vp, _i, _i, _IP, _vp, _i, _i, _IP, _vp, _IP]),
+    "dlaf_mi355x_pdhegst": (None, [_i, _ch, _i, _vp, _i, _i, _IP, _vp, _i, _i, _IP, _vp, _IP]),
+    "dlaf_mi355x_pchegst": (None, [_i, _ch, _i, _vp, _i, _i, _IP, _vp, _i, _i, _IP, _vp, _IP]),
+    "dlaf_mi355x_pzhegst": (None, [_i, _ch, _i, _vp, _i, _i, _IP, _vp, _i, _i, _IP, _vp, _IP]),
+    "dlaf_mi355x_generalized_to_standard_device": (_i, [_vp, _vp]),
     "dlaf_mi355x_set_random_hpd": (_i, [_i, _ch, _vp, DLAFDescriptor, _i]),
     "dlaf_mi355x_tile_potrf": (_i, [_ch, _ch, _i, _vp, _i]),
     "dlaf_mi355x_tile_trsm": (_i, [_ch, _ch, _i, _i, _vp, _i, _vp, _i]),

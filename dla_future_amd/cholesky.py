@@ -204,6 +204,37 @@ def pxpotrs(uplo: str, n: int, nrhs: int, a: np.ndarray, ia: int, ja: int, desca
     return info.value
 
 
+def generalized_to_standard(grid: Grid, uplo: str, a: np.ndarray, b: np.ndarray, nb: int, isrc: int = 0, jsrc: int = 0,
+                            n: int | None = None) -> int:
+    """dlaf::eigensolver::internal::generalized_to_standard(grid, uplo, mat_a, mat_b)
+    (include/dlaf/eigensolver/gen_to_std.h:50, :101) == dlaf_mi355x_generalized_to_standard_{s,d,c,z}:
+    `a` (this process's local part of the Hermitian A) is overwritten by inv(L) A inv(L^H) (uplo 'L') or
+    inv(U^H) A inv(U) (uplo 'U') in its uplo triangle; `b` holds the Cholesky factor of B in the same triangle."""
+    t = type_char(a.dtype)
+    if a.dtype != b.dtype:
+        raise ValueError("A and B must have the same element type")
+    if n is None:
+        if grid.nranks != 1:
+            raise ValueError("the global size n is required on a distributed grid")
+        n = a.shape[0]
+    da = make_descriptor(n, nb, _ld_of(a), isrc, jsrc)
+    db = make_descriptor(n, nb, _ld_of(b), isrc, jsrc)
+    return getattr(lib(), f"dlaf_mi355x_generalized_to_standard_{t}")(grid.context, uplo.encode(), _ptr(a), da, _ptr(b), db)
+
+
+def pxhegst(ibtype: int, uplo: str, n: int, a: np.ndarray, ia: int, ja: int, desca, b: np.ndarray, ib: int, jb: int,
+            descb):
+    """dlaf_mi355x_p{s,d,c,z}hegst: ScaLAPACK's p?sygst / p?hegst argument list; returns (scale, info)."""
+    t = type_char(a.dtype)
+    da = (C.c_int * 9)(*[int(x) for x in desca])
+    db = (C.c_int * 9)(*[int(x) for x in descb])
+    scale = (C.c_float if t in "sc" else C.c_double)(-1)
+    info = C.c_int(-999)
+    getattr(lib(), f"dlaf_mi355x_p{t}hegst")(ibtype, uplo.encode(), n, _ptr(a), ia, ja, da, _ptr(b), ib, jb, db,
+                                             C.byref(scale), C.byref(info))
+    return scale.value, info.value
+
+
 def solver_profile():
     """(ms, flops) of the sweep of the last triangular solve on this process (device time, no staging)."""
     ms, fl = C.c_double(0), C.c_double(0)
@@ -273,6 +304,10 @@ class DeviceMatrix:
     def factorize(self) -> int:
         """dlaf::cholesky_factorization<Backend::GPU, Device::GPU, T> on the resident matrix; blocking."""
         return lib().dlaf_mi355x_cholesky_factorization_device(self._h)
+
+    def generalized_to_standard(self, factor_of_b: "DeviceMatrix") -> int:
+        """`self` (Hermitian A, resident) <- inv(L) A inv(L^H) with the resident Cholesky factor of B."""
+        return lib().dlaf_mi355x_generalized_to_standard_device(self._h, factor_of_b._h)
 
     def start(self) -> None:
         lib().dlaf_mi355x_cholesky_start(self._h)

@@ -48,6 +48,16 @@ struct UpdateArgs {
   int b_period = 1;
   long b_ts2 = 0;
   int b_jl0 = -1;  // local tile column that b stands for (-1: jl0)
+  // Two-segment product (K1 > 0): columns k < K1 of the operands come from a / b, columns K1 <= k < K from
+  // a2 / b2 (same tile strides and leading dimensions): two panels applied in one pass
+  //     C -= A1 B1^H + A2 B2^H            (one read-modify-write of C for two steps of the factorization)
+  // her2k != 0 (needs K1 > 0): with a = [X | L], b = [L | X] the launch computes C -= X L^H + L X^H; diagonal
+  // tiles take their column operand from the column panel again with the segments swapped ([L_j | X_j]) and
+  // keep the triangle mask (tile::her2k of gen_to_std).
+  int K1 = 0;
+  const T* a2 = nullptr;
+  const T* b2 = nullptr;
+  int her2k = 0;
 };
 // role: 0 trailing bulk, 1 lookahead column, 2 in-tile POTRF update / single-tile entries, 3 residual checker
 // and triangular solver (same code, separate kernel names, so that profiles of the factorization stay clean)
@@ -144,6 +154,13 @@ void launch_from_tiles(const LayoutArgs<T>& args, hipStream_t stream);
 template <class T>
 void launch_copy2d(T* dst, long ldd, const T* src, long lds, int rows, int cols, int transpose, int mask,
                    hipStream_t stream);
+
+// Batched tile transforms (gen_to_std): tile t at src + t*sstride (rows x cols, lds) -> dst + t*dstride.
+//   mode 0: dst = src^H (cols x rows);  mode 1: dst = scale * (full Hermitian image of src's lower triangle);
+//   mode 2: lower(dst) = lower(src^H), rest of dst untouched, real diagonal.
+template <class T>
+void launch_tile_xform(T* dst, long ldd, long dstride, const T* src, long lds, long sstride, int rows, int cols,
+                       int count, int mode, double scale, hipStream_t stream);
 
 // checker helpers: max |a_ij| over the lower triangle of the local tiles (into *out, device double) and
 // zeroing of the strict upper part of the local diagonal tiles

@@ -135,6 +135,72 @@ void launch_copy2d(T* dst, long ldd, const T* src, long lds, int rows, int cols,
                      mask);
 }
 
+// ---- tile transforms of gen_to_std (eigensolver/gen_to_std/impl.h): batches of square-ish tiles ----------
+//   mode 0: dst = src^H                                  (rows x cols -> cols x rows), every element
+//   mode 1: dst = scale * H, H the Hermitian matrix whose lower triangle is src's (imag(diag) taken as 0)
+//   mode 2: lower(dst) = lower(src^H), strictly upper part of dst untouched, imag(diag) = 0
+template <class T>
+__global__ __launch_bounds__(kThreads) void tile_xform_kernel(T* dst, long ldd, long dstride, const T* src, long lds,
+                                                              long sstride, int rows, int cols, int mode,
+                                                              real_t<T> scale) {
+  using R = real_t<T>;
+  __shared__ T t[32][33];
+  const int tile = blockIdx.z;
+  const T* s = src + (long) tile * sstride;
+  T* d = dst + (long) tile * dstride;
+  const int tx = threadIdx.x % 32, ty = threadIdx.x / 32;  // 32 x 8
+  const int bi = blockIdx.x * 32, bj = blockIdx.y * 32;    // block origin in SRC coordinates (row bi, col bj)
+  auto conj_of = [](T v) {
+    if constexpr (TypeInfo<T>::is_complex)
+      v.im = -v.im;
+    return v;
+  };
+  if (mode == 1) {
+    // element (i, j) of the full Hermitian image: from (i, j) if i >= j, else conj of (j, i); coalesced writes
+    for (int jj = ty; jj < 32; jj += 8) {
+      const int i = bi + tx, j = bj + jj;
+      if (i < rows && j < cols) {
+        T v = (i >= j) ? s[i + (long) j * lds] : conj_of(s[j + (long) i * lds]);
+        if (i == j)
+          v = make_el<T>(re_of(v), R(0));
+        d[i + (long) j * ldd] = make_el<T>(scale * re_of(v), scale * im_of(v));
+      }
+    }
+    return;
+  }
+  // modes 0 / 2: transpose through LDS (coalesced reads and writes)
+  for (int jj = ty; jj < 32; jj += 8) {
+    const int i = bi + tx, j = bj + jj;
+    if (i < rows && j < cols)
+      t[jj][tx] = s[i + (long) j * lds];
+  }
+  __syncthreads();
+  for (int ii = ty; ii < 32; ii += 8) {
+    // dst element (row = src col, col = src row)
+    const int dr = bj + tx, dc = bi + ii;
+    if (dr < cols && dc < rows) {
+      T v = conj_of(t[tx][ii]);
+      if (mode == 2) {
+        if (dr < dc)
+          continue;
+        if (dr == dc)
+          v = make_el<T>(re_of(v), R(0));
+      }
+      d[dr + (long) dc * ldd] = v;
+    }
+  }
+}
+
+template <class T>
+void launch_tile_xform(T* dst, long ldd, long dstride, const T* src, long lds, long sstride, int rows, int cols,
+                       int count, int mode, double scale, hipStream_t stream) {
+  if (rows <= 0 || cols <= 0 || count <= 0)
+    return;
+  dim3 grid((unsigned) ((rows + 31) / 32), (unsigned) ((cols + 31) / 32), (unsigned) count);
+  hipLaunchKernelGGL((tile_xform_kernel<T>), grid, dim3(kThreads), 0, stream, dst, ldd, dstride, src, lds, sstride, rows,
+                     cols, mode, (real_t<T>) scale);
+}
+
 // ---- checker helpers (miniapp/miniapp_cholesky.cpp:243-259 setUpperToZeroForDiagonalTiles,
 // include/dlaf/auxiliary/norm/mc.h max_norm) -------------------------------------------------------
 // one workgroup per local tile: max |a_ij| over the tiles with global row >= global column (lower part of
@@ -232,6 +298,7 @@ void device_kernels_init() {
   template void launch_to_tiles<T>(const LayoutArgs<T>&, hipStream_t);         \
   template void launch_from_tiles<T>(const LayoutArgs<T>&, hipStream_t);     \
   template void launch_copy2d<T>(T*, long, const T*, long, int, int, int, int, hipStream_t);    \
+  template void launch_tile_xform<T>(T*, long, long, const T*, long, long, int, int, int, int, double, hipStream_t); \
   template void launch_max_norm<T>(const T*, int, int, int, long, long, int, int, int, int, double*, hipStream_t); \
   template void launch_zero_upper_diag<T>(T*, int, int, int, int, int, int, int, hipStream_t);
 INST(float)

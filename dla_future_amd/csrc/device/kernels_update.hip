@@ -119,23 +119,48 @@ __device__ __forceinline__ void update_block(const UpdateArgs<T>& p, const Updat
   const T* A = p.a + (long) (il - p.il0) * p.a_ts + m0;
   // herk on a diagonal tile reads the COLUMN panel for both operands (impl.h:282-287): the
   // transposed panel never holds the tile of the last global row (broadcast_panel.h:186-191)
+  // her2k (gen_to_std): C_jj -= X_j L_j^H + L_j X_j^H with a = [X | L]: the column operand of a diagonal
+  // tile is the column panel again, segments swapped ([L_j | X_j])
   const int jt = jl - (p.b_jl0 >= 0 ? p.b_jl0 : p.jl0);
-  const T* B = diag ? p.a + (long) (il - p.il0) * p.a_ts + n0
-                    : p.b + (long) (jt % p.b_period) * p.b_ts2 + (long) (jt / p.b_period) * p.b_ts + n0;
+  const long boff = (long) (jt % p.b_period) * p.b_ts2 + (long) (jt / p.b_period) * p.b_ts;
+  const long aoff = (long) (il - p.il0) * p.a_ts;
+  const T* B;
+  const T* B2 = nullptr;
   const long ldb = diag ? p.lda : p.ldb;
+  if (!diag) {
+    B = p.b + boff + n0;
+    if (p.K1 > 0)
+      B2 = p.b2 + boff + n0;
+  }
+  else if (!p.her2k) {
+    B = p.a + aoff + n0;
+    if (p.K1 > 0)
+      B2 = p.a2 + aoff + n0;
+  }
+  else {
+    B = p.a2 + aoff + n0;
+    B2 = p.a + aoff + n0;
+  }
+  int K1 = 1 << 30;
+  const T* A2 = nullptr;
+  if (p.K1 > 0) {
+    K1 = p.K1;
+    A2 = p.a2 + aoff + m0 - (long) K1 * p.lda;
+    B2 -= (long) K1 * ldb;
+  }
 #ifdef DLAF_DBG_SAME_STRIPS
   A = p.a;  // tuning aid (tools/update_bench.hip): every block streams the same two strips = perfect L2 locality
   B = p.b;
 #endif
   T* C = p.c + (long) il * p.c_tsr + (long) jl * p.c_tsc + m0 + (long) n0 * p.ldc;
 
-  const bool full = (mrows == Cfg::BM) && (ncols == Cfg::BN) && (p.K % Cfg::BK == 0);
+  const bool full = (mrows == Cfg::BM) && (ncols == Cfg::BN) && (p.K % Cfg::BK == 0) && (p.K1 % Cfg::BK == 0);
   Acc<Cfg> acc;
   acc.clear();
   if (full)
-    gemm_nt_block<Cfg, T, VEC, false>(A, p.lda, mrows, B, ldb, ncols, p.K, lds, acc);
+    gemm_nt_block<Cfg, T, VEC, false>(A, p.lda, mrows, B, ldb, ncols, p.K, lds, acc, K1, A2, B2);
   else
-    gemm_nt_block<Cfg, T, false, true>(A, p.lda, mrows, B, ldb, ncols, p.K, lds, acc);
+    gemm_nt_block<Cfg, T, false, true>(A, p.lda, mrows, B, ldb, ncols, p.K, lds, acc, K1, A2, B2);
 
 #ifdef DLAF_DBG_SKIP_EPILOGUE
   {
@@ -363,7 +388,8 @@ void launch_update(const UpdateArgs<T>& a, hipStream_t stream, int role, long ma
     (void) hipMemsetAsync(counters, 0, 8 * sizeof(unsigned), stream);
   }
   const bool vec = aligned16<T>(a.a, a.lda) && aligned16<T>(a.a, a.a_ts) && aligned16<T>(a.b, a.ldb) &&
-                   aligned16<T>(a.b, a.b_ts) && aligned16<T>(a.b, a.b_ts2);
+                   aligned16<T>(a.b, a.b_ts) && aligned16<T>(a.b, a.b_ts2) &&
+                   (a.K1 == 0 || (aligned16<T>(a.a2, 0) && aligned16<T>(a.b2, 0)));
   auto go = [&](auto vtag, auto rtag) {
     constexpr bool V = decltype(vtag)::value;
     constexpr int RL = decltype(rtag)::value;

@@ -211,10 +211,15 @@ __device__ __forceinline__ void stage_glds(const T* __restrict__ A, long lda, co
 // acc += A(mrows x K) * B(ncols x K)^H for one BM x BN block.  lds: 2 * BUF_ELEMS of R.
 // EDGE: rows >= mrows / ncols and k >= K are zero-filled; otherwise mrows == BM, ncols == BN and
 // K % BK == 0 are the caller's promise.  All threads of the workgroup must call it.
+// Two-segment form: columns k >= K1 of both operands come from A2 / B2 (same leading dimensions): the
+// product of two panels applied in one pass (K = K1 + K2, one epilogue), or the two products of a her2k.
+// A2 / B2 are passed already shifted back by K1 columns, K1 is a multiple of BK; K1 >= K: one segment.
 template <class Cfg, class T, bool VEC, bool EDGE>
 __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda, int mrows,
                                               const T* __restrict__ B, long ldb, int ncols, int K,
-                                              typename Cfg::R* __restrict__ lds, Acc<Cfg>& acc) {
+                                              typename Cfg::R* __restrict__ lds, Acc<Cfg>& acc, int K1 = 1 << 30,
+                                              const T* __restrict__ A2 = nullptr,
+                                              const T* __restrict__ B2 = nullptr) {
   using R = typename Cfg::R;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -232,7 +237,8 @@ __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda,
 #pragma unroll
     for (int s = 0; s < ST - 1; ++s)
       if (s < nk)
-        stage_glds<Cfg, T>(A, lda, B, ldb, s * Cfg::BK, lds + s * Cfg::BUF_ELEMS, wave, lane);
+        stage_glds<Cfg, T>(s * Cfg::BK < K1 ? A : A2, lda, s * Cfg::BK < K1 ? B : B2, ldb, s * Cfg::BK,
+                           lds + s * Cfg::BUF_ELEMS, wave, lane);
     // slab 0 must be complete: everything but the younger (ST-2) slabs
     if (nk >= ST - 1)
       __builtin_amdgcn_s_waitcnt(0x0070 | ((LPS * (ST - 2)) & 0xF) | ((((LPS * (ST - 2)) >> 4) & 0x3) << 14));
@@ -245,8 +251,10 @@ __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda,
 #ifdef DLAF_DBG_SKIP_GLOBAL
       cur = lds;
 #else
-      if (kt + ST - 1 < nk)
-        stage_glds<Cfg, T>(A, lda, B, ldb, (kt + ST - 1) * Cfg::BK, lds + nxt_i * Cfg::BUF_ELEMS, wave, lane);
+      if (kt + ST - 1 < nk) {
+        const int kn = (kt + ST - 1) * Cfg::BK;
+        stage_glds<Cfg, T>(kn < K1 ? A : A2, lda, kn < K1 ? B : B2, ldb, kn, lds + nxt_i * Cfg::BUF_ELEMS, wave, lane);
+      }
 #endif
       mma_slab<Cfg>(cur, cur + Cfg::A_ELEMS, acc, wm, wn, lane);
       // next slab (kt+1) landed?  loads still allowed in flight: those of slabs kt+2 .. kt+ST-1
@@ -264,8 +272,8 @@ __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda,
   }
   Slab<T, Cfg::BM, Cfg::BK, VEC, Cfg::LDA, Cfg::CXI, Cfg::THREADS> sa;
   Slab<T, Cfg::BN, Cfg::BK, VEC, Cfg::LDB, Cfg::CXI, Cfg::THREADS> sb;
-  sa.template load<EDGE>(A, lda, 0, mrows, K);
-  sb.template load<EDGE>(B, ldb, 0, ncols, K);
+  sa.template load<EDGE>(0 < K1 ? A : A2, lda, 0, mrows, K);
+  sb.template load<EDGE>(0 < K1 ? B : B2, ldb, 0, ncols, K);
   sa.store(lds);
   sb.store(lds + Cfg::A_ELEMS);
   __syncthreads();
@@ -279,8 +287,9 @@ __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda,
     const bool more = (kt + 1) < nk;
 #endif
     if (more) {
-      sa.template load<EDGE>(A, lda, (kt + 1) * Cfg::BK, mrows, K);
-      sb.template load<EDGE>(B, ldb, (kt + 1) * Cfg::BK, ncols, K);
+      const int kn = (kt + 1) * Cfg::BK;
+      sa.template load<EDGE>(kn < K1 ? A : A2, lda, kn, mrows, K);
+      sb.template load<EDGE>(kn < K1 ? B : B2, ldb, kn, ncols, K);
     }
     mma_slab<Cfg>(cur, cur + Cfg::A_ELEMS, acc, wm, wn, lane);
     if (more) {

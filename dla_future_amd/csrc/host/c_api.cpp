@@ -193,6 +193,46 @@ void pxpotrs(char uplo, int n, int nrhs, const HT* a, int ia, int ja, const int 
     *info = 0;
 }
 
+// dlaf::eigensolver::internal::generalized_to_standard (include/dlaf/eigensolver/gen_to_std.h:50,:101) through
+// descriptors: preconditions of gen_to_std.h:52-60 / :103-113 (square, square blocks, same size and blocks)
+template <class HT>
+int gen_to_std_c(int ctx, char uplo, HT* a, const DLAF_descriptor& da, const HT* b, const DLAF_descriptor& db) {
+  using DT = typename DevType<HT>::type;
+  check_cholesky_desc(da);
+  check_cholesky_desc(db);
+  if (!(uplo == 'L' || uplo == 'l' || uplo == 'U' || uplo == 'u'))
+    fatal("[dlaf_mi355x] uplo must be 'L' or 'U', got '%c'\n", uplo);
+  if (da.m != db.m || da.nb != db.nb || da.isrc != db.isrc || da.jsrc != db.jsrc)
+    fatal("[dlaf_mi355x] gen_to_std: A (%d, block %d, source %d,%d) and B (%d, block %d, source %d,%d) must be "
+          "distributed alike\n", da.m, da.nb, da.isrc, da.jsrc, db.m, db.nb, db.isrc, db.jsrc);
+  Grid& g = grid_from_context(ctx);
+  if (da.isrc < 0 || da.isrc >= g.nprow || da.jsrc < 0 || da.jsrc >= g.npcol)
+    fatal("[dlaf_mi355x] source rank (%d,%d) outside the %d x %d grid\n", da.isrc, da.jsrc, g.nprow, g.npcol);
+  return gen_to_std_host<DT>(&g, uplo, reinterpret_cast<DT*>(a), da.ld, reinterpret_cast<const DT*>(b), db.ld, da.m,
+                             da.nb, da.isrc, da.jsrc);
+}
+
+// ScaLAPACK p?sygst / p?hegst argument list (ibtype 1 only: inv(L) A inv(L^H) / inv(U^H) A inv(U))
+template <class HT, class RT>
+void pxhegst(int ibtype, char uplo, int n, HT* a, int ia, int ja, const int desca[9], const HT* b, int ib, int jb,
+             const int descb[9], RT* scale, int* info) {
+  if (ibtype != 1)
+    fatal("[dlaf_mi355x] p?hegst: only ibtype = 1 is built (got %d)\n", ibtype);
+  if (desca[0] != 1 || descb[0] != 1)
+    fatal("[dlaf_mi355x] desc[0] (dtype) must be 1\n");
+  if (ia != 1 || ja != 1 || ib != 1 || jb != 1)
+    fatal("[dlaf_mi355x] ia, ja, ib, jb must be 1\n");
+  if (desca[1] != descb[1])
+    fatal("[dlaf_mi355x] A and B live on different contexts (%d, %d)\n", desca[1], descb[1]);
+  const DLAF_descriptor da = make_dlaf_descriptor(n, n, ia, ja, desca);
+  const DLAF_descriptor db = make_dlaf_descriptor(n, n, ib, jb, descb);
+  const int r = gen_to_std_c<HT>(desca[1], uplo, a, da, b, db);
+  if (scale)
+    *scale = RT(1);
+  if (info)
+    *info = r;
+}
+
 struct MatrixHandle {
   std::unique_ptr<MatrixBase> m;
   char type;
@@ -425,6 +465,22 @@ DLAF_MI355X_TRSM_ENTRY(c, std::complex<float>, dlaf_complex_c)
 DLAF_MI355X_TRSM_ENTRY(z, std::complex<double>, dlaf_complex_z)
 #undef DLAF_MI355X_TRSM_ENTRY
 
+#define DLAF_MI355X_HEGST_ENTRY(S, HT, CT, RT)                                                                    \
+  int dlaf_mi355x_generalized_to_standard_##S(int ctx, char uplo, CT* a, DLAF_descriptor desca, const CT* b,       \
+                                              DLAF_descriptor descb) noexcept {                                  \
+    return gen_to_std_c<HT>(ctx, uplo, reinterpret_cast<HT*>(a), desca, reinterpret_cast<const HT*>(b), descb);    \
+  }                                                                                                              \
+  void dlaf_mi355x_p##S##hegst(int ibtype, char uplo, int n, CT* a, int ia, int ja, const int desca[9], const CT* b, \
+                               int ib, int jb, const int descb[9], RT* scale, int* info) noexcept {               \
+    pxhegst<HT, RT>(ibtype, uplo, n, reinterpret_cast<HT*>(a), ia, ja, desca, reinterpret_cast<const HT*>(b), ib, \
+                    jb, descb, scale, info);                                                                     \
+  }
+DLAF_MI355X_HEGST_ENTRY(s, float, float, float)
+DLAF_MI355X_HEGST_ENTRY(d, double, double, double)
+DLAF_MI355X_HEGST_ENTRY(c, std::complex<float>, dlaf_complex_c, float)
+DLAF_MI355X_HEGST_ENTRY(z, std::complex<double>, dlaf_complex_z, double)
+#undef DLAF_MI355X_HEGST_ENTRY
+
 int dlaf_mi355x_solver_profile(double* ms, double* flops) noexcept {
   solver_last_profile(ms, flops);
   return 0;
@@ -503,6 +559,12 @@ int dlaf_mi355x_cholesky_residual(dlaf_mi355x_matrix_t original, dlaf_mi355x_mat
   if (!original || !factor || original->type != factor->type)
     return -1;
   WITH_MATRIX(original, M.residual_of(static_cast<DeviceMatrix<DT>&>(*factor->m), max_diff, max_a); return 0;)
+}
+
+int dlaf_mi355x_generalized_to_standard_device(dlaf_mi355x_matrix_t a, dlaf_mi355x_matrix_t l) noexcept {
+  if (!a || !l || a->type != l->type)
+    return -1;
+  WITH_MATRIX(a, return gen_to_std_device(M, static_cast<DeviceMatrix<DT>&>(*l->m));)
 }
 
 int dlaf_mi355x_matrix_profile(dlaf_mi355x_matrix_t h, int kind, double* ms, long* launches, double* flops,

@@ -640,6 +640,14 @@ void DeviceMatrix<T>::factorize_async() {
       return std::strcmp(e, "sidecar") == 0 && !dist;
     return !dist && !TypeInfo<T>::is_complex && nb <= 768;
   }();
+  // one process: the bulk update takes the panels of TWO steps per pass (K = 2 nb): half the read-modify-write
+  // traffic of the trailing matrix, half the launches, half the per-block epilogues -- what a small block
+  // size loses against nb = 1024 (DLAF_MI355X_SCHEDULE=pairs; default for one process, real types, nb <= 768)
+  const bool pairs = [&] {
+    if (const char* e = std::getenv("DLAF_MI355X_SCHEDULE"))
+      return std::strcmp(e, "pairs") == 0 && !dist;
+    return !dist && !TypeInfo<T>::is_complex && nb <= 768 && nb % 16 == 0;
+  }();
   const long sidecar_slots = [&]() -> long {
     if (const char* e = std::getenv("DLAF_MI355X_SIDECAR_SLOTS"))
       return std::atol(e);
@@ -686,6 +694,11 @@ void DeviceMatrix<T>::factorize_async() {
     long b_ts = 0, il_n = 0, jl_n = 0;
     int b_period = 1;  // transposed panel grouped by root process row: see bcast_transposed_panel
     long b_ts2 = 0;
+    // two panels applied in one pass (one process, "pairs" order): columns k1 .. kb-1 of the operands are
+    // the panel of the following step
+    const T* a2_base = nullptr;
+    const T* b2_base = nullptr;
+    int k1 = 0;
     int kb = 0;
     long rest0 = 0, split = 0;  // classic: rest_A = [rest0, split), rest_B = [split, ltc); early: rest = [rest0, ltc)
     bool valid = false;
@@ -716,6 +729,11 @@ void DeviceMatrix<T>::factorize_async() {
     ua.b_period = st.b_period;
     ua.b_ts2 = st.b_ts2;
     ua.b_jl0 = (int) st.jl_n;
+    if (st.k1 > 0) {
+      ua.K1 = st.k1;
+      ua.a2 = st.a2_base + (size_t) (il0 - st.il_n) * tile_elems;
+      ua.b2 = st.b2_base;
+    }
     ua.ldb = nb;
     ua.il0 = (int) il0;
     ua.il1 = (int) il1;
@@ -844,7 +862,67 @@ void DeviceMatrix<T>::factorize_async() {
 
   Step prev;  // step k-1, whose bulk update is still to be issued (in part or in full)
 
-  if (sidecar) {
+  if (pairs) {
+    // s_main : LA(p-1) . rest(p-1) ............................................ LA(p) . rest(p) ...
+    // s_panel:           POTRF(k) . TRSM(k) . U1(k -> col k+1) . POTRF(k+1) . TRSM(k+1)
+    // pair p = steps (k, k+1); LA(p) = the two-panel update of tile columns k+2, k+3 (what the next pair's
+    // panels need), rest(p) = columns >= k+4 as one persistent launch that leaves `sidecar_slots` free.
+    auto single = [&](long k) {  // the one-panel step of step k (operands of U1)
+      Step st;
+      st.valid = true;
+      st.kb = rows.tile_extent(k);
+      st.il_n = st.jl_n = k + 1;
+      st.a_base = tile(k + 1 < ltr ? k + 1 : 0, k);
+      st.b_base = st.a_base;
+      st.b_ts = (long) tile_elems;
+      return st;
+    };
+    for (long k = 0; k < nt; k += 2) {
+      if (tr)
+        tr->mark(k);
+      if (k >= 2)
+        DLAF_HIP_CHECK(hipStreamWaitEvent(s_panel, ev_high[k - 2], 0));  // LA(p-1): columns k, k+1 are final
+      potrf(k);
+      const bool second = k + 1 < nt;       // the pair has a second step
+      if (second) {
+        trsm(k + 1, ltr, k, tile(k, k), winv_of(k), rows.tile_extent(k), s_panel);
+        DLAF_HIP_CHECK(hipEventRecord(ev_panel[k], s_panel));
+        panels_issued.store(k, std::memory_order_release);
+        update(single(k), k + 1, k + 2, s_panel, 1, 0);
+        potrf(k + 1);
+      }
+      const bool more = k + 2 < nt;         // something trails the pair
+      if (more) {
+        trsm(k + 2, ltr, k + 1, tile(k + 1, k + 1), winv_of(k + 1), rows.tile_extent(k + 1), s_panel);
+        DLAF_HIP_CHECK(hipEventRecord(ev_panel[k + 1], s_panel));
+        panels_issued.store(k + 1, std::memory_order_release);
+      }
+      // the bulk of the previous pair runs beside all of the above
+      update(prev, prev.rest0, ltc, s_main, 0, sidecar_slots);
+      prev.valid = false;
+      if (!more) {
+        DLAF_HIP_CHECK(hipEventRecord(ev_diag[k], s_panel));
+        DLAF_HIP_CHECK(hipStreamWaitEvent(s_main, ev_diag[k], 0));
+        break;
+      }
+      DLAF_HIP_CHECK(hipStreamWaitEvent(s_main, ev_panel[k + 1], 0));
+      Step cur;
+      cur.valid = true;
+      cur.il_n = cur.jl_n = k + 2;
+      cur.k1 = rows.tile_extent(k);
+      cur.kb = cur.k1 + rows.tile_extent(k + 1);
+      cur.a_base = tile(k + 2, k);
+      cur.a2_base = tile(k + 2, k + 1);
+      cur.b_base = cur.a_base;
+      cur.b2_base = cur.a2_base;
+      cur.b_ts = (long) tile_elems;
+      update(cur, k + 2, std::min<long>(k + 4, ltc), s_main, 1, 0);
+      DLAF_HIP_CHECK(hipEventRecord(ev_high[k], s_main));
+      cur.rest0 = std::min<long>(k + 4, ltc);
+      prev = cur;
+    }
+  }
+  else if (sidecar) {
     for (long k = 0; k < nt; ++k) {
       const int kb = rows.tile_extent(k);
       if (tr)

@@ -213,6 +213,13 @@ int triangular_solver_host(Grid* g, char side, char uplo, char op, char diag, T 
 
 void solver_last_profile(double* ms, double* flops);
 
+// A <- L^-1 A L^-H (uplo L) / U^-H A U^-1 (uplo U) with the Cholesky factor held in the same uplo triangle of
+// `l` (gen_to_std.cpp; dlaf::eigensolver::internal::generalized_to_standard); device-resident and host forms
+template <class T>
+int gen_to_std_device(DeviceMatrix<T>& a, DeviceMatrix<T>& l);
+template <class T>
+int gen_to_std_host(Grid* g, char uplo, T* a, long lda, const T* l, long ldl, long n, int nb, int isrc, int jsrc);
+
 void runtime_init();
 void runtime_finalize();
 bool runtime_initialized();

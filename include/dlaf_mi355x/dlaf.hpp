@@ -377,6 +377,42 @@ void triangular_solver(blas::Side side, blas::Uplo uplo, blas::Op op, blas::Diag
   triangular_solver<B, D, T>(grid, side, uplo, op, diag, alpha, mat_a, mat_b);
 }
 
+// include/dlaf/eigensolver/gen_to_std.h:50, :101: A <- inv(L) A inv(L^H) (Lower) / inv(U^H) A inv(U) (Upper) with
+// the Cholesky factor of B in mat_b (host-resident operands; only the uplo triangles are referenced)
+namespace eigensolver::internal {
+template <Backend B, class T>
+void generalized_to_standard(comm::CommunicatorGrid& grid, blas::Uplo uplo, Matrix<T, Device::CPU>& mat_a,
+                             Matrix<T, Device::CPU>& mat_b) {
+  static_assert(B == Backend::GPU, "this library has no CPU backend");
+  auto desc_of = [](const Matrix<T, Device::CPU>& m) {
+    const auto& d = m.distribution();
+    return DLAF_descriptor{(int) d.size().rows(), (int) d.size().cols(), (int) d.block_size().rows(),
+                           (int) d.block_size().cols(), (int) d.source_rank_index().row(),
+                           (int) d.source_rank_index().col(), 0, 0, (int) m.ld()};
+  };
+  int r;
+  if constexpr (std::is_same_v<T, float>)
+    r = dlaf_mi355x_generalized_to_standard_s(grid.context(), (char) uplo, mat_a.ptr(), desc_of(mat_a), mat_b.ptr(),
+                                              desc_of(mat_b));
+  else if constexpr (std::is_same_v<T, double>)
+    r = dlaf_mi355x_generalized_to_standard_d(grid.context(), (char) uplo, mat_a.ptr(), desc_of(mat_a), mat_b.ptr(),
+                                              desc_of(mat_b));
+  else if constexpr (std::is_same_v<T, std::complex<float>>)
+    r = dlaf_mi355x_generalized_to_standard_c(grid.context(), (char) uplo, mat_a.ptr(), desc_of(mat_a), mat_b.ptr(),
+                                              desc_of(mat_b));
+  else
+    r = dlaf_mi355x_generalized_to_standard_z(grid.context(), (char) uplo, mat_a.ptr(), desc_of(mat_a), mat_b.ptr(),
+                                              desc_of(mat_b));
+  if (r != 0)
+    dlaf::internal::fail("generalized_to_standard");
+}
+template <Backend B, class T>
+void generalized_to_standard(blas::Uplo uplo, Matrix<T, Device::CPU>& mat_a, Matrix<T, Device::CPU>& mat_b) {
+  comm::CommunicatorGrid grid = comm::CommunicatorGrid::single();
+  generalized_to_standard<B, T>(grid, uplo, mat_a, mat_b);
+}
+}  // namespace eigensolver::internal
+
 // include/dlaf/init.h: the library needs no runtime arguments; initialize / finalize are idempotent
 inline void initialize(int argc = 0, const char** argv = nullptr) { dlaf_initialize(argc, argv, 0, nullptr); }
 inline void finalize() { dlaf_finalize(); }

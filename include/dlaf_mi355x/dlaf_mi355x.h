@@ -154,6 +154,39 @@ DLAF_EXTERN_C void dlaf_mi355x_pzpotrs(char uplo, int n, int nrhs, const dlaf_co
                                        const int desca[9], dlaf_complex_z* b, int ib, int jb, const int descb[9],
                                        int* info) DLAF_NOEXCEPT;
 
+/* ---- generalized -> standard eigenproblem ------------------------------------------- */
+/* dlaf::eigensolver::internal::generalized_to_standard(grid, uplo, A, B), include/dlaf/eigensolver/gen_to_std.h:50,
+ * :101 (LAPACK xHEGST itype 1; the reference has no C entry for it):  A <- inv(L) A inv(L^H) (uplo 'L') or
+ * inv(U^H) A inv(U) (uplo 'U'), where b holds the Cholesky factor of B in its uplo triangle (dlaf_p?potrf output).
+ * Only the uplo triangles are read / written; b is not modified.  A and B must be distributed alike (size, square
+ * block, source process).  Returns 0.  The p?hegst names take ScaLAPACK's p?sygst / p?hegst argument list
+ * (ibtype must be 1; *scale is set to 1). */
+DLAF_EXTERN_C int dlaf_mi355x_generalized_to_standard_s(int context, char uplo, float* a, struct DLAF_descriptor desca,
+                                                        const float* b, struct DLAF_descriptor descb) DLAF_NOEXCEPT;
+DLAF_EXTERN_C int dlaf_mi355x_generalized_to_standard_d(int context, char uplo, double* a, struct DLAF_descriptor desca,
+                                                        const double* b, struct DLAF_descriptor descb) DLAF_NOEXCEPT;
+DLAF_EXTERN_C int dlaf_mi355x_generalized_to_standard_c(int context, char uplo, dlaf_complex_c* a,
+                                                        struct DLAF_descriptor desca, const dlaf_complex_c* b,
+                                                        struct DLAF_descriptor descb) DLAF_NOEXCEPT;
+DLAF_EXTERN_C int dlaf_mi355x_generalized_to_standard_z(int context, char uplo, dlaf_complex_z* a,
+                                                        struct DLAF_descriptor desca, const dlaf_complex_z* b,
+                                                        struct DLAF_descriptor descb) DLAF_NOEXCEPT;
+DLAF_EXTERN_C void dlaf_mi355x_pshegst(int ibtype, char uplo, int n, float* a, int ia, int ja, const int desca[9],
+                                       const float* b, int ib, int jb, const int descb[9], float* scale,
+                                       int* info) DLAF_NOEXCEPT;
+DLAF_EXTERN_C void dlaf_mi355x_pdhegst(int ibtype, char uplo, int n, double* a, int ia, int ja, const int desca[9],
+                                       const double* b, int ib, int jb, const int descb[9], double* scale,
+                                       int* info) DLAF_NOEXCEPT;
+DLAF_EXTERN_C void dlaf_mi355x_pchegst(int ibtype, char uplo, int n, dlaf_complex_c* a, int ia, int ja,
+                                       const int desca[9], const dlaf_complex_c* b, int ib, int jb,
+                                       const int descb[9], float* scale, int* info) DLAF_NOEXCEPT;
+DLAF_EXTERN_C void dlaf_mi355x_pzhegst(int ibtype, char uplo, int n, dlaf_complex_z* a, int ia, int ja,
+                                       const int desca[9], const dlaf_complex_z* b, int ib, int jb,
+                                       const int descb[9], double* scale, int* info) DLAF_NOEXCEPT;
+/* the same on device-resident matrices (both created with the same uplo on the same grid) */
+DLAF_EXTERN_C int dlaf_mi355x_generalized_to_standard_device(dlaf_mi355x_matrix_t a,
+                                                             dlaf_mi355x_matrix_t cholesky_factor_of_b) DLAF_NOEXCEPT;
+
 /* Device time (ms, HIP events on the compute stream) of the sweep of the last triangular solve on this process
  * -- relayout and PCIe staging excluded -- and the whole-grid algorithmic flops it stands for (m n^2 for side
  * R, m^2 n for side L; x4 complex). */

@@ -394,3 +394,122 @@ def check_near(expected: np.ndarray, actual: np.ndarray, rel: float, abs_: float
         relok = np.where(abs_max > 0, diff / np.where(abs_max > 0, abs_max, 1), np.inf) < rel
     ok = (diff < abs_) | relok
     return bool(ok.all()), (float(diff.max()) if diff.size else 0.0)
+
+
+# ---- generalized -> standard eigenproblem ---------------------------------------------
+# Reference: GenToStd::call_L (include/dlaf/eigensolver/gen_to_std/impl.h:222-283), tile::hegst
+# (include/dlaf/lapack/tile.h:209-218 -> lapack::hegst = LAPACK xHEGST/xHEGS2 itype 1), known answers
+# getGenToStdElementSetters (test/include/dlaf_test/matrix/util_generic_lapack.h:96-150).
+def gen_to_std_setters(uplo: str, n: int, dtype, alpha: float = -2.0, beta: float = 1.5, gamma: float = 0.95):
+    """(T, A, B) of getGenToStdElementSetters, itype 1 (test_gen_to_std.cpp:68-70 uses alpha -2, beta 1.5,
+    gamma .95): T the triangular factor, A the input, B = inv(L) A inv(L^H) (uplo L) / inv(U^H) A inv(U) (uplo U);
+    -9.9 in the triangle that must not be touched."""
+    dt = np.dtype(dtype)
+    cx = np.issubdtype(dt, np.complexfloating)
+    i, j = np.meshgrid(np.arange(n, dtype=np.float64), np.arange(n, dtype=np.float64), indexing="ij")
+    ph = np.exp(1j * alpha * (i - j)) if cx else np.ones_like(i)
+    t = (beta / np.exp2(np.abs(i - j))) * ph
+    a = ((i + 1) * (j + 1) * (beta * beta * gamma) / np.exp2(i + j)) * ph
+    b = (gamma / np.exp2(i + j)) * ph
+    other = (i < j) if uplo in "Ll" else (i > j)
+    out = []
+    for m in (t, a, b):
+        m = np.where(other, -9.9, m)
+        out.append(np.asfortranarray(m.astype(dt)))
+    return tuple(out)
+
+
+def hegst_tile(uplo: str, a: np.ndarray, b: np.ndarray) -> None:
+    """tile::hegst(itype 1, uplo, a, b) = LAPACK xHEGS2: a <- inv(L) a inv(L^H) (uplo L, b = L) or inv(U^H) a inv(U)
+    (uplo U, b = U), unblocked, in place on the uplo triangle of a (the other triangle is never referenced).
+    The upper variant is the lower algorithm on the transposed storage (B^T = L'^-1 A^T L'^-H with L' = U^T)."""
+    n = a.shape[0]
+    if uplo in "Uu":
+        at = np.asfortranarray(a.T.copy())
+        hegst_tile("L", at, np.asfortranarray(b.T.copy()))
+        iu = np.triu_indices(n)
+        a[iu] = at.T[iu]
+        return
+    real = a.real.dtype.type
+    for k in range(n):
+        bkk = real(b[k, k].real)
+        akk = real(a[k, k].real) / (bkk * bkk)
+        a[k, k] = akk
+        if k < n - 1:
+            x = a[k + 1:, k]
+            lcol = b[k + 1:, k]
+            x *= real(1) / bkk
+            ct = real(-0.5) * akk
+            x += ct * lcol
+            # her2, lower: A22 -= x l^H + l x^H
+            upd = np.outer(x, lcol.conj()) + np.outer(lcol, x.conj())
+            sub = a[k + 1:, k + 1:]
+            il = np.tril_indices(n - k - 1)
+            sub[il] -= upd[il]
+            d = np.arange(n - k - 1)
+            sub[d, d] = sub[d, d].real
+            x += ct * lcol
+            # trsv: x <- inv(L22) x (lower, no transpose, non-unit)
+            l22 = b[k + 1:, k + 1:]
+            for r in range(n - k - 1):
+                x[r] = (x[r] - np.dot(l22[r, :r], x[:r])) / l22[r, r]
+
+
+def gen_to_std_local(uplo: str, a: np.ndarray, l: np.ndarray, nb: int) -> None:
+    """GenToStd::call_L (impl.h:222-283) tile by tile, in place on the uplo triangle of `a`; `l` holds the Cholesky
+    factor in the same triangle and is only read.  uplo U (call_U, the mirrored loop) runs as the lower algorithm
+    on the transposed storage."""
+    n = a.shape[0]
+    if n == 0:
+        return
+    if uplo in "Uu":
+        at = np.asfortranarray(a.T.copy())
+        gen_to_std_local("L", at, np.asfortranarray(l.T.copy()), nb)
+        iu = np.triu_indices(n)
+        a[iu] = at.T[iu]
+        return
+    nt = (n + nb - 1) // nb
+
+    def tl(m, i, j):
+        return m[i * nb:min(n, (i + 1) * nb), j * nb:min(n, (j + 1) * nb)]
+
+    def herm(t):
+        h = np.tril(t) + np.tril(t, -1).conj().T
+        d = np.arange(h.shape[0])
+        h[d, d] = h[d, d].real
+        return h
+
+    half = a.real.dtype.type(0.5)
+    for k in range(nt):
+        akk, lkk = tl(a, k, k), tl(l, k, k)
+        tmp = np.asfortranarray(akk.copy())
+        hegst_tile("L", tmp, np.asfortranarray(lkk))                       # hegstDiagTile
+        il = np.tril_indices(tmp.shape[0])
+        akk[il] = tmp[il]
+        if k == nt - 1:
+            continue
+        akk_full = herm(akk)
+        lkk_f = np.asfortranarray(np.tril(lkk))
+        for i in range(k + 1, nt):
+            aik = np.asfortranarray(tl(a, i, k).copy())
+            trsm("R", "L", "C", "N", 1.0, lkk_f, aik)                       # trsmPanelTile
+            aik -= half * (tl(l, i, k) @ akk_full)                          # hemmPanelTile
+            tl(a, i, k)[...] = aik
+        for j in range(k + 1, nt):
+            ajk, ljk = tl(a, j, k), tl(l, j, k)
+            ajj = tl(a, j, j)
+            upd = ajk @ ljk.conj().T + ljk @ ajk.conj().T                   # her2kTrailingDiagTile
+            ilj = np.tril_indices(ajj.shape[0])
+            ajj[ilj] -= upd[ilj]
+            d = np.arange(ajj.shape[0])
+            ajj[d, d] = ajj[d, d].real
+            for i in range(j + 1, nt):                                      # gemmTrailingMatrixTile x 2
+                tl(a, i, j)[...] -= tl(a, i, k) @ ljk.conj().T + tl(l, i, k) @ ajk.conj().T
+        for i in range(k + 1, nt):
+            tl(a, i, k)[...] -= half * (tl(l, i, k) @ akk_full)             # hemmPanelTile
+        for j in range(k + 1, nt):
+            ajk = np.asfortranarray(tl(a, j, k).copy())
+            trsm("L", "L", "N", "N", 1.0, np.asfortranarray(np.tril(tl(l, j, j))), ajk)   # trsmPanelUpdateTile
+            tl(a, j, k)[...] = ajk
+            for i in range(j + 1, nt):
+                tl(a, i, k)[...] -= tl(l, i, j) @ ajk                       # gemmPanelUpdateTile

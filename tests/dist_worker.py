@@ -229,6 +229,48 @@ def main():
                         print(f"[dist_worker] solver FAILED {t} {side}{uplo}{op}{diag} {m}x{n} nb={nb} "
                               f"grid {nprow}x{npcol}: max diff {md} tol {tol}", flush=True)
                     ok &= bool(good)
+        # generalized_to_standard on the grid: the reference's distributed test (test_gen_to_std.cpp:85-113) --
+        # analytic operands, non-zero source rank, abs tolerance 10 (m+1) error, the factor untouched -- plus
+        # random operands against the oracle's restatement of GenToStd::call_L
+        for t, uplo, m, mb in [("d", "L", 34, 13), ("d", "U", 34, 13), ("z", "L", 32, 5), ("z", "U", 16, 10), ("s", "L", 34, 34),
+                               ("c", "U", 5, 8), ("d", "L", 4, 3), ("d", "L", 0, 2), ("d", "U", 200, 32), ("z", "L", 150, 32)]:
+            dt = oracle.DTYPES[t]
+            sr, sc = max(0, nprow - 1), min(1, npcol - 1)
+            tmat, a, b = oracle.gen_to_std_setters(uplo, m, dt)
+            la = np.asfortranarray(oracle.scatter(a, mb, nprow, npcol, sr, sc, extra_ld=1)[(grid.myrow, grid.mycol)])
+            lt = np.asfortranarray(oracle.scatter(tmat, mb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
+            lt0 = lt.copy(order="F")
+            ok &= dlaf.generalized_to_standard(grid, uplo, la, lt, mb, sr, sc, n=m) == 0
+            got = gather_global(la, grid, m, mb, sr, sc, oracle)
+            ok &= bool(np.array_equal(lt, lt0))
+            if rank == 0:
+                err = (8 if t in "cz" else 2) * oracle.eps_of(dt)
+                good, md = oracle.check_near(b, got, 0, 10 * (m + 1) * err)
+                if not good:
+                    print(f"[dist_worker] gen_to_std FAILED {t}{uplo} m={m} mb={mb} grid {nprow}x{npcol}: max diff {md}", flush=True)
+                ok &= bool(good)
+        for t, uplo, n, nb in [("d", "L", 530, 64), ("z", "U", 300, 32)]:
+            dt = oracle.DTYPES[t]
+            sr, sc = 0, 0
+            b0 = oracle.set_random_hpd(n, nb, dt)
+            a0 = (oracle.set_random_hpd(n, nb, dt) * dt(1.0 / n)).astype(dt)
+            fac = b0.copy(order="F")
+            assert oracle.cholesky_local(uplo, fac, nb) == 0
+            la = np.asfortranarray(oracle.scatter(a0, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
+            lf = np.asfortranarray(oracle.scatter(fac, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
+            ok &= dlaf.generalized_to_standard(grid, uplo, la, lf, nb, sr, sc, n=n) == 0
+            got = gather_global(la, grid, n, nb, sr, sc, oracle)
+            if rank == 0:
+                ref = a0.copy(order="F")
+                oracle.gen_to_std_local(uplo, ref, fac, nb)
+                err = (8 if t in "cz" else 2) * oracle.eps_of(dt)
+                tol = 10 * (n + 1) * err * max(1.0, np.abs(oracle.tri(uplo, ref)).max())
+                good, md = oracle.check_near(oracle.tri(uplo, ref), oracle.tri(uplo, got), 0, tol)
+                other = np.triu(got, 1) if uplo == "L" else np.tril(got, -1)
+                good &= bool(np.array_equal(other, np.triu(a0, 1) if uplo == "L" else np.tril(a0, -1)))
+                if not good:
+                    print(f"[dist_worker] gen_to_std random FAILED {t}{uplo} n={n} nb={nb}: max diff {md} tol {tol}", flush=True)
+                ok &= bool(good)
         # analytic known-answer matrix through the ScaLAPACK-style entry (test_cholesky_c_api.cpp:108-155)
         n, nb = 34, 13
         a, l = oracle.cholesky_setters("L", n, np.float64)

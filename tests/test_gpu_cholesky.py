@@ -41,11 +41,11 @@ def test_cholesky_local_analytic(dlaf, grid, oracle, t, uplo):
         assert (store[m:, :] == 4.4).all()
 
 
-@pytest.fixture(params=["classic", "early", "sidecar"])
+@pytest.fixture(params=["classic", "early", "sidecar", "pairs"])
 def schedule(request, monkeypatch):
-    """The issue orders of the tile DAG (runtime.cpp: classic / sidecar = one-process defaults for large /
-    small blocks, early diagonal = process-grid default); DLAF_MI355X_SCHEDULE is read at every
-    factorization."""
+    """The issue orders of the tile DAG (runtime.cpp: classic / pairs = one-process defaults for large /
+    small blocks, sidecar = the round-1 small-block order, early diagonal = process-grid default);
+    DLAF_MI355X_SCHEDULE is read at every factorization."""
     monkeypatch.setenv("DLAF_MI355X_SCHEDULE", request.param)
     return request.param
 

@@ -392,3 +392,42 @@ def test_baseline_matches_oracle(oracle):
     assert oracle.baseline_cholesky_d(got, nb, 4) == 0
     assert np.allclose(np.tril(got), np.tril(ref), rtol=1e-13, atol=1e-13)
     assert np.array_equal(np.triu(got, 1), np.triu(a0, 1))
+
+
+# ---- gen_to_std: the restatement against the reference's known answers and LAPACK ---------
+GEN_TO_STD_SIZES = [(0, 2), (5, 8), (34, 34), (4, 3), (16, 10), (34, 13), (32, 5)]  # test_gen_to_std.cpp:54-58
+
+
+@pytest.mark.parametrize("t", ["s", "d", "c", "z"])
+@pytest.mark.parametrize("uplo", ["L", "U"])
+def test_gen_to_std_oracle_reproduces_the_reference_known_answers(oracle, t, uplo):
+    """getGenToStdElementSetters (util_generic_lapack.h:96-150) with the parameters and the tolerance of
+    test_gen_to_std.cpp:68-83: abs 10 (m + 1) error, other triangle untouched (-9.9)."""
+    dt = oracle.DTYPES[t]
+    err = (8 if t in "cz" else 2) * oracle.eps_of(dt)
+    for m, mb in GEN_TO_STD_SIZES:
+        tmat, a, b = oracle.gen_to_std_setters(uplo, m, dt)
+        got = a.copy(order="F")
+        oracle.gen_to_std_local(uplo, got, tmat, mb)
+        ok, md = oracle.check_near(b, got, 0, 10 * (m + 1) * err)
+        assert ok, (m, mb, md)
+
+
+def test_gen_to_std_oracle_matches_lapack_hegst(oracle):
+    """Independent numeric answer: LAPACK xSYGST / xHEGST (itype 1) through scipy on random operands."""
+    import scipy.linalg.lapack as la
+    for t, fn in (("d", la.dsygst), ("z", la.zhegst)):
+        dt = oracle.DTYPES[t]
+        n, nb = 70, 16
+        b0 = oracle.set_random_hpd(n, nb, dt)
+        a0 = oracle.set_random_hpd(n, nb, dt) * dt(0.01)
+        for uplo in "LU":
+            fac = b0.copy(order="F")
+            assert oracle.cholesky_local(uplo, fac, nb) == 0
+            got = a0.copy(order="F")
+            oracle.gen_to_std_local(uplo, got, fac, nb)
+            ref, info = fn(a0.copy(order="F"), fac, itype=1, lower=1 if uplo == "L" else 0)
+            assert info == 0
+            assert np.abs(oracle.tri(uplo, ref) - oracle.tri(uplo, got)).max() < 50 * n * oracle.eps_of(dt)
+            other = np.triu(got, 1) if uplo == "L" else np.tril(got, -1)
+            assert np.array_equal(other, np.triu(a0, 1) if uplo == "L" else np.tril(a0, -1))

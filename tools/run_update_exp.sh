@@ -24,8 +24,9 @@ if [ "${PMC:-0}" = "1" ]; then
   for v in $VARIANTS; do
     name=${v%%:*}
     rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 \
-      --kernel-trace -d $GRAFT_REPO_ROOT/$OUT/pmc_$name -o pmc -- /tmp/ub_$name 48 1024 2 > $GRAFT_REPO_ROOT/$OUT/pmc_$name.log 2>&1
-    python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $GRAFT_REPO_ROOT/$OUT/pmc_$name update_kernel | tee -a $GRAFT_REPO_ROOT/$OUT/pmc_summary.txt
-    rm -rf $GRAFT_REPO_ROOT/$OUT/pmc_$name
+      --kernel-trace --output-format csv -d /tmp/pmc_$name -- /tmp/ub_$name 48 1024 2 > $GRAFT_REPO_ROOT/$OUT/pmc_$name.log 2>&1
+    find /tmp/pmc_$name -name "*.csv" | head -5 >> $GRAFT_REPO_ROOT/$OUT/pmc_$name.log
+    echo "## $name" | tee -a $GRAFT_REPO_ROOT/$OUT/pmc_summary.txt
+    python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py /tmp/pmc_$name update_kernel | tee -a $GRAFT_REPO_ROOT/$OUT/pmc_summary.txt
   done
 fi
