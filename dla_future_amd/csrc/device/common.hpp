@@ -134,16 +134,18 @@ struct Slab {
 
   T regs[NL][VE];
 
-  // rows_valid / k_valid only read when EDGE
+  // rows_valid / k_valid only read when EDGE.  Two-segment operands (EDGE only): columns >= k1 come from src2
+  // (passed shifted back by k1 columns), whatever k1 is -- a slab may straddle it.
   template <bool EDGE>
-  __device__ __forceinline__ void load(const T* __restrict__ src, long ld, int k0, int rows_valid, int k_valid) {
+  __device__ __forceinline__ void load(const T* __restrict__ src, long ld, int k0, int rows_valid, int k_valid,
+                                       const T* __restrict__ src2 = nullptr, int k1 = 1 << 30) {
     const int t = threadIdx.x;
 #pragma unroll
     for (int q = 0; q < NL; ++q) {
       const int idx = t + THREADS * q;
       const int r = (idx % (ROWS / VE)) * VE;
       const int k = idx / (ROWS / VE);
-      const T* p = src + r + (long) (k0 + k) * ld;
+      const T* p = ((EDGE && (k0 + k) >= k1) ? src2 : src) + r + (long) (k0 + k) * ld;
       if constexpr (!EDGE) {
         if constexpr (VE == 1) {
           regs[q][0] = *p;

@@ -7,6 +7,10 @@
 
 namespace dlaf_mi355x {
 
+#ifdef DLAF_DBG_STAMPS
+__device__ unsigned long long g_dbg_stamps[8];
+#endif
+
 // PAIRED_ (real types): MFMA tiles 2q and 2q+1 of a wave hold the even / odd rows of a 32-row group,
 // so one 16-byte LDS read feeds two fragments and the epilogue moves two consecutive rows per lane
 // (16-byte global accesses).  With it the LDS image is unpadded ([k][ROWS], column stride = 0 mod
@@ -71,10 +75,18 @@ struct Acc {
 };
 
 // one BK-slab of MFMAs out of the LDS images As ([k][LDA], planes re|im) and Bs ([k][LDB])
-template <class Cfg>
+struct NoHook {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+
+// hook(p) is called before each group of TM MFMAs (p = k4 * TN + j counts the groups of a slab): the
+// direct-to-LDS pipeline issues its loads of a later slab there, one at a time in the shadow of the MFMAs,
+// instead of as one block at the head of the iteration (8 x global_load_lds back to back keep the wave from
+// issuing MFMAs for ~1k cycles per slab; measured with in-kernel stamps, tools/update_bench.hip)
+template <class Cfg, class Hook = NoHook>
 __device__ __forceinline__ void mma_slab(const typename Cfg::R* __restrict__ As,
                                          const typename Cfg::R* __restrict__ Bs, Acc<Cfg>& acc, int wm,
-                                         int wn, int lane) {
+                                         int wn, int lane, Hook&& hook = Hook{}) {
   using R = typename Cfg::R;
   const int g = lane >> 4, c = lane & 15;
 #pragma unroll
@@ -126,7 +138,8 @@ __device__ __forceinline__ void mma_slab(const typename Cfg::R* __restrict__ As,
       }
     }
 #pragma unroll
-    for (int j = 0; j < Cfg::TN; ++j)
+    for (int j = 0; j < Cfg::TN; ++j) {
+      hook(k4 * Cfg::TN + j);
 #pragma unroll
       for (int i = 0; i < Cfg::TM; ++i) {
         // D[i' = n][j' = m]: Aop <- B panel fragment, Bop <- A panel fragment
@@ -138,6 +151,7 @@ __device__ __forceinline__ void mma_slab(const typename Cfg::R* __restrict__ As,
           acc.im[i][j] = Mma<R>::mma(b_im[j], -a_re[i], acc.im[i][j]);
         }
       }
+    }
   }
 }
 
@@ -165,11 +179,12 @@ template <class Cfg, class T>
 __device__ __forceinline__ void stage_glds(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb, int k0,
                                            typename Cfg::R* __restrict__ buf, int wave, int lane) {
   constexpr int NA = Cfg::PIECES_A / Cfg::NWAVES, NB = Cfg::PIECES_B / Cfg::NWAVES;  // instructions per wave
+  constexpr int QA0 = 0, QA1 = NA, QB0 = 0, QB1 = NB;
   if constexpr (Cfg::CXI) {
     // 16-byte elements: one instruction moves 64 rows of one column; wave w takes every NWAVES-th piece
     constexpr int PA = Cfg::BM / 64, PB = Cfg::BN / 64;
 #pragma unroll
-    for (int idx = 0; idx < NA; ++idx) {
+    for (int idx = QA0; idx < QA1; ++idx) {
       const int piece = wave + Cfg::NWAVES * idx;
       const int k = piece / PA, part = piece % PA;
       const T* ga = A + part * 64 + lane + (long) (k0 + k) * lda;
@@ -178,7 +193,7 @@ __device__ __forceinline__ void stage_glds(const T* __restrict__ A, long lda, co
                                        16, 0, 0);
     }
 #pragma unroll
-    for (int idx = 0; idx < NB; ++idx) {
+    for (int idx = QB0; idx < QB1; ++idx) {
       const int piece = wave + Cfg::NWAVES * idx;
       const int k = piece / PB, part = piece % PB;
       const T* gb = B + part * 64 + lane + (long) (k0 + k) * ldb;
@@ -191,7 +206,7 @@ __device__ __forceinline__ void stage_glds(const T* __restrict__ A, long lda, co
   constexpr int PER = 16 / (int) sizeof(T);  // elements per lane
   constexpr int EPP = Cfg::EPP;              // elements per piece
 #pragma unroll
-  for (int q = 0; q < NA; ++q) {
+  for (int q = QA0; q < QA1; ++q) {
     const int e0 = (wave * NA + q) * EPP;    // first element of the piece in the image [k][BM]
     const int e = e0 + lane * PER;
     const T* ga = A + (e % Cfg::BM) + (long) (k0 + e / Cfg::BM) * lda;
@@ -199,8 +214,32 @@ __device__ __forceinline__ void stage_glds(const T* __restrict__ A, long lda, co
                                      (__attribute__((address_space(3))) void*) (buf + e0), 16, 0, 0);
   }
 #pragma unroll
-  for (int q = 0; q < NB; ++q) {
+  for (int q = QB0; q < QB1; ++q) {
     const int e0 = (wave * NB + q) * EPP;
+    const int e = e0 + lane * PER;
+    const T* gb = B + (e % Cfg::BN) + (long) (k0 + e / Cfg::BN) * ldb;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) gb,
+                                     (__attribute__((address_space(3))) void*) (buf + Cfg::A_ELEMS + e0), 16, 0, 0);
+  }
+}
+
+// The IDX-th of the LPS instructions stage_glds issues for this wave (real types), alone: lets the pipelined
+// loop spread them over the MFMA stream.
+template <class Cfg, class T, int IDX>
+__device__ __forceinline__ void stage_glds_one(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb,
+                                               int k0, typename Cfg::R* __restrict__ buf, int wave, int lane) {
+  static_assert(!Cfg::CXI, "real types");
+  constexpr int NA = Cfg::PIECES_A / Cfg::NWAVES, NB = Cfg::PIECES_B / Cfg::NWAVES;
+  constexpr int PER = 16 / (int) sizeof(T), EPP = Cfg::EPP;
+  if constexpr (IDX < NA) {
+    const int e0 = (wave * NA + IDX) * EPP;
+    const int e = e0 + lane * PER;
+    const T* ga = A + (e % Cfg::BM) + (long) (k0 + e / Cfg::BM) * lda;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) ga,
+                                     (__attribute__((address_space(3))) void*) (buf + e0), 16, 0, 0);
+  }
+  else if constexpr (IDX < NA + NB) {
+    const int e0 = (wave * NB + (IDX - NA)) * EPP;
     const int e = e0 + lane * PER;
     const T* gb = B + (e % Cfg::BN) + (long) (k0 + e / Cfg::BN) * ldb;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) gb,
@@ -245,6 +284,84 @@ __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda,
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#ifndef DLAF_GLDS_INTERLEAVE
+#define DLAF_GLDS_INTERLEAVE 0
+#endif
+#if DLAF_GLDS_INTERLEAVE
+    int cur_i = 0, nxt_i = ST - 1;
+#ifdef DLAF_DBG_STAMPS
+    // tuning aid (tools/update_bench.hip): where a K-loop iteration spends its cycles, per wave
+    unsigned long long st_issue = 0, st_mma = 0, st_vm = 0, st_bar = 0;
+#endif
+    // The loads of slab kt+ST-1 are issued inside the MFMA stream of slab kt, one share per 4-deep step, and
+    // without a branch: past the end the LAST slab is fetched again into the ring slot that was consumed an
+    // iteration ago (never read again; drained after the loop).  The wait count is then the same every time.
+    constexpr bool SPLIT = !Cfg::CXI && LPS <= (Cfg::BK / 4) * Cfg::TN && LPS <= 16;
+    for (int kt = 0; kt < nk; ++kt) {
+#ifdef DLAF_DBG_STAMPS
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
+      R* cur = lds + cur_i * Cfg::BUF_ELEMS;
+#ifdef DLAF_DBG_SKIP_GLOBAL
+      cur = lds;
+      mma_slab<Cfg>(cur, cur + Cfg::A_ELEMS, acc, wm, wn, lane);
+#else
+      const int kn = min(kt + ST - 1, nk - 1) * Cfg::BK;
+      const T* An = kn < K1 ? A : A2;
+      const T* Bn = kn < K1 ? B : B2;
+      R* nbuf = lds + nxt_i * Cfg::BUF_ELEMS;
+      if constexpr (SPLIT) {
+        mma_slab<Cfg>(cur, cur + Cfg::A_ELEMS, acc, wm, wn, lane, [&](int p) {
+          // (p is a compile-time constant after unrolling: the chain folds to the one instruction of group p)
+#define DLAF_GLDS_AT(I)                                                                   \
+  if (p == I) {                                                                         \
+    if constexpr (I < LPS)                                                              \
+      stage_glds_one<Cfg, T, (I < LPS ? I : 0)>(An, lda, Bn, ldb, kn, nbuf, wave, lane); \
+  }
+          DLAF_GLDS_AT(0) DLAF_GLDS_AT(1) DLAF_GLDS_AT(2) DLAF_GLDS_AT(3) DLAF_GLDS_AT(4) DLAF_GLDS_AT(5) DLAF_GLDS_AT(6)
+          DLAF_GLDS_AT(7) DLAF_GLDS_AT(8) DLAF_GLDS_AT(9) DLAF_GLDS_AT(10) DLAF_GLDS_AT(11) DLAF_GLDS_AT(12)
+          DLAF_GLDS_AT(13) DLAF_GLDS_AT(14) DLAF_GLDS_AT(15)
+#undef DLAF_GLDS_AT
+        });
+      }
+      else {
+        stage_glds<Cfg, T>(An, lda, Bn, ldb, kn, nbuf, wave, lane);
+        mma_slab<Cfg>(cur, cur + Cfg::A_ELEMS, acc, wm, wn, lane);
+      }
+#endif
+#ifdef DLAF_DBG_STAMPS
+      const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+#endif
+      // slab kt+1 landed?  still in flight afterwards: the loads of slabs kt+2 .. kt+ST-1
+      __builtin_amdgcn_s_waitcnt(0x0070 | ((LPS * (ST - 2)) & 0xF) | ((((LPS * (ST - 2)) >> 4) & 0x3) << 14));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef DLAF_DBG_STAMPS
+      const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+#endif
+      __builtin_amdgcn_s_barrier();
+#ifdef DLAF_DBG_STAMPS
+      const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+      st_mma += t2 - t0;
+      st_vm += t3 - t2;
+      st_bar += t4 - t3;
+#endif
+      cur_i = (cur_i + 1 == ST) ? 0 : cur_i + 1;
+      nxt_i = (nxt_i + 1 == ST) ? 0 : nxt_i + 1;
+    }
+    // the re-fetched slabs of the last ST-1 iterations: nobody reads them, but they must have landed before the
+    // caller reuses the ring
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#ifdef DLAF_DBG_STAMPS
+    if (lane == 0) {
+      atomicAdd(&g_dbg_stamps[0], st_issue);
+      atomicAdd(&g_dbg_stamps[1], st_mma);
+      atomicAdd(&g_dbg_stamps[2], st_vm);
+      atomicAdd(&g_dbg_stamps[3], st_bar);
+      atomicAdd(&g_dbg_stamps[4], 1ull);
+    }
+#endif
+#else
     int cur_i = 0, nxt_i = ST - 1;
     for (int kt = 0; kt < nk; ++kt) {
       R* cur = lds + cur_i * Cfg::BUF_ELEMS;
@@ -268,12 +385,14 @@ __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda,
       cur_i = (cur_i + 1 == ST) ? 0 : cur_i + 1;
       nxt_i = (nxt_i + 1 == ST) ? 0 : nxt_i + 1;
     }
+#endif
     return;
   }
   Slab<T, Cfg::BM, Cfg::BK, VEC, Cfg::LDA, Cfg::CXI, Cfg::THREADS> sa;
   Slab<T, Cfg::BN, Cfg::BK, VEC, Cfg::LDB, Cfg::CXI, Cfg::THREADS> sb;
-  sa.template load<EDGE>(0 < K1 ? A : A2, lda, 0, mrows, K);
-  sb.template load<EDGE>(0 < K1 ? B : B2, ldb, 0, ncols, K);
+  // (EDGE: the slab picks its source column by column, K1 need not be a multiple of BK)
+  sa.template load<EDGE>(0 < K1 ? A : A2, lda, 0, mrows, K, A2, K1);
+  sb.template load<EDGE>(0 < K1 ? B : B2, ldb, 0, ncols, K, B2, K1);
   sa.store(lds);
   sb.store(lds + Cfg::A_ELEMS);
   __syncthreads();
@@ -288,8 +407,8 @@ __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda,
 #endif
     if (more) {
       const int kn = (kt + 1) * Cfg::BK;
-      sa.template load<EDGE>(kn < K1 ? A : A2, lda, kn, mrows, K);
-      sb.template load<EDGE>(kn < K1 ? B : B2, ldb, kn, ncols, K);
+      sa.template load<EDGE>(kn < K1 ? A : A2, lda, kn, mrows, K, A2, K1);
+      sb.template load<EDGE>(kn < K1 ? B : B2, ldb, kn, ncols, K, B2, K1);
     }
     mma_slab<Cfg>(cur, cur + Cfg::A_ELEMS, acc, wm, wn, lane);
     if (more) {

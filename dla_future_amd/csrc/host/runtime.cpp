@@ -642,11 +642,12 @@ void DeviceMatrix<T>::factorize_async() {
   }();
   // one process: the bulk update takes the panels of TWO steps per pass (K = 2 nb): half the read-modify-write
   // traffic of the trailing matrix, half the launches, half the per-block epilogues -- what a small block
-  // size loses against nb = 1024 (DLAF_MI355X_SCHEDULE=pairs; default for one process, real types, nb <= 768)
+  // size loses against nb = 1024, and 1.5 % at nb = 1024 itself (DLAF_MI355X_SCHEDULE=pairs; default for one
+  // process, real types; measured fp64: N=32768 nb=512 55.0 -> 57.2 TFlop/s, N=65536 nb=1024 64.9 -> 65.9)
   const bool pairs = [&] {
     if (const char* e = std::getenv("DLAF_MI355X_SCHEDULE"))
       return std::strcmp(e, "pairs") == 0 && !dist;
-    return !dist && !TypeInfo<T>::is_complex && nb <= 768 && nb % 16 == 0;
+    return !dist && !TypeInfo<T>::is_complex && nb % 16 == 0;
   }();
   const long sidecar_slots = [&]() -> long {
     if (const char* e = std::getenv("DLAF_MI355X_SIDECAR_SLOTS"))
@@ -877,6 +878,45 @@ void DeviceMatrix<T>::factorize_async() {
       st.b_ts = (long) tile_elems;
       return st;
     };
+    // Workgroup slots rest(p-1) leaves free for the panel work of pair p running beside it: too few and the
+    // panel chain (2 POTRF + 2 TRSM, throughput ~ slots) outlasts the bulk, too many and the bulk loses that
+    // share of the GPU for its whole duration.  Chosen per pair from a two-line cost model (rates measured on
+    // MI355X); DLAF_MI355X_SIDECAR_SLOTS fixes it.
+    // (measured: the fixed reservation of 32 slots beat this model at N=32768 nb=512 -- 57.2 vs 54.8 TFlop/s --
+    // and tied it at N=65536 nb=1024, so the model is opt-in: DLAF_MI355X_ADAPTIVE_SLOTS=1)
+    const bool slots_fixed = std::getenv("DLAF_MI355X_ADAPTIVE_SLOTS") == nullptr;
+    auto pair_slots = [&](long k, const Step& bulk) -> long {
+      if (slots_fixed || !bulk.valid || bulk.rest0 >= ltc)
+        return sidecar_slots;
+      const bool cxt = TypeInfo<T>::is_complex, dbl = sizeof(real_t<T>) == 8;
+      const double r_bulk = (dbl ? 66e12 : 118e12) * (cxt && !dbl ? 1.1 : 1.0);
+      const double r_trsm = dbl ? (cxt ? 23e12 : 50e12) : 60e12;
+      double fl_b = 0, by;
+      for (long jl = bulk.rest0; jl < ltc; ++jl) {
+        double f;
+        update_work(std::max(bulk.il_n, rows.next_local(cols.global_of(jl))), ltr, jl, jl + 1, bulk.kb, f, by);
+        fl_b += f;
+      }
+      const double cxf = cxt ? 4.0 : 1.0;
+      const double below = (double) std::max<long>(0, n - (k + 1) * (long) nb) + (double) std::max<long>(0, n - (k + 2) * (long) nb);
+      const double fl_t = cxf * (double) nb * nb * below;
+      const double nblk = (double) nb / kDiagBlock;
+      const double t_potrf = 2.0 * nblk * nblk * 13.7e-6 * (cxt ? 2.0 : 1.0);
+      const long lo = std::max<long>(potrf_slots, 8);
+      long best = std::max(lo, sidecar_slots);
+      double best_t = 1e30;
+      for (long cand : {8L, 16L, 24L, 32L, 48L, 64L, 96L, 128L, 192L, 256L}) {
+        if (cand < lo || cand >= bulk_slots)
+          continue;
+        const double share = (double) cand / (double) bulk_slots;
+        const double t = std::max(fl_b / (r_bulk * (1.0 - share)), t_potrf + fl_t / (r_trsm * share));
+        if (t < best_t) {
+          best_t = t;
+          best = cand;
+        }
+      }
+      return best;
+    };
     for (long k = 0; k < nt; k += 2) {
       if (tr)
         tr->mark(k);
@@ -898,7 +938,7 @@ void DeviceMatrix<T>::factorize_async() {
         panels_issued.store(k + 1, std::memory_order_release);
       }
       // the bulk of the previous pair runs beside all of the above
-      update(prev, prev.rest0, ltc, s_main, 0, sidecar_slots);
+      update(prev, prev.rest0, ltc, s_main, 0, pair_slots(k, prev));
       prev.valid = false;
       if (!more) {
         DLAF_HIP_CHECK(hipEventRecord(ev_diag[k], s_panel));

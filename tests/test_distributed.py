@@ -49,6 +49,15 @@ def launch(mode, nprow, npcol, order, timeout, extra_env=None):
             if p.poll() is None:
                 p.kill()  # exact PIDs we started
     rc = [p.returncode for p in procs]
+    if not (all(r == 0 for r in rc) and "DIST_WORKER_RESULT OK" in outs[0][0]):
+        # the whole story of a failing run goes to a file (pytest truncates long assertion messages)
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", f"dist_fail_{mode}_{nprow}x{npcol}.log"), "w") as fh:
+                for r, (o, e) in enumerate(outs):
+                    fh.write(f"==== rank {r} rc={rc[r]}\n-- stdout\n{o}\n-- stderr\n{e[-6000:]}\n")
+        except OSError:
+            pass
     assert all(r == 0 for r in rc) and "DIST_WORKER_RESULT OK" in outs[0][0], \
         (rc, outs[0][0][-2000:], "\n".join(o[1][-1500:] for o in outs))
 

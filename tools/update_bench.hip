@@ -22,7 +22,11 @@ int main(int argc, char** argv) {
   const long max_blocks = argc > 4 ? atol(argv[4]) : 0;  // > 0: persistent grid of that many workgroups
   update_kernels_init();
   printf("resident workgroups per CU (occupancy API): %d\n", update_blocks_per_cu<TT>());
-  const size_t te = (size_t) nb * nb;
+#ifndef UB_LDPAD
+#define UB_LDPAD 0
+#endif
+  const int ld = nb + UB_LDPAD;  // leading dimension of a tile (UB_LDPAD != 0: no power-of-two column stride)
+  const size_t te = (size_t) ld * nb;
   TT* tiles;
   int* info;
   (void) hipMalloc(&tiles, sizeof(TT) * te * nt * nt);
@@ -37,13 +41,13 @@ int main(int argc, char** argv) {
   ua.c = tiles;
   ua.c_tsr = (long) te;
   ua.c_tsc = (long) te * nt;
-  ua.ldc = nb;
+  ua.ldc = ld;
   ua.a = tiles + te;  // column 0, rows 1..
   ua.a_ts = (long) te;
-  ua.lda = nb;
+  ua.lda = ld;
   ua.b = tiles + te;
   ua.b_ts = (long) te;
-  ua.ldb = nb;
+  ua.ldb = ld;
   ua.il0 = ua.jl0 = 1;
   ua.il1 = ua.jl1 = nt;
   ua.nb = nb;
@@ -72,5 +76,25 @@ int main(int argc, char** argv) {
     (void) hipEventElapsedTime(&ms, e0, e1);
     printf("nt=%d nb=%d max_blocks=%ld: %.3f ms  %.2f TFlop/s\n", nt, nb, max_blocks, ms, flops / ms / 1e9);
   }
+#ifdef DLAF_DBG_STAMPS
+  {
+    unsigned long long z[8] = {0}, h[8];
+    (void) hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_stamps), z, sizeof(z));
+    hipEvent_t a0, a1;
+    (void) hipEventCreate(&a0);
+    (void) hipEventCreate(&a1);
+    (void) hipEventRecord(a0);
+    launch_update(ua, nullptr, 0, max_blocks, ctr);
+    (void) hipEventRecord(a1);
+    (void) hipDeviceSynchronize();
+    float ms;
+    (void) hipEventElapsedTime(&ms, a0, a1);
+    (void) hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg_stamps), sizeof(h));
+    const double tot = (double) (h[0] + h[1] + h[2] + h[3]);
+    printf("stamps (instrumented run %.3f ms): wave-blocks %llu; per K-loop share: issue glds %.1f %%, ds_read+mfma %.1f %%, "
+           "vmcnt/lgkm wait %.1f %%, barrier %.1f %%; mean cycles per wave-block %.0f\n",
+           ms, h[4], 100.0 * h[0] / tot, 100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot, tot / (double) h[4]);
+  }
+#endif
   return 0;
 }
