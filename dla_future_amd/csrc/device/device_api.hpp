@@ -114,10 +114,15 @@ void launch_invert_diag_blocks(const T* tile, int ld, int kb, T* winv, int* info
 
 // Whole diagonal tile (kb x kb, ld) in one resident cooperative launch of ceil(kb/64) workgroups:
 // lower Cholesky factor in place + the ceil(kb/64) inverted diagonal blocks in winv.  sync: device
-// scratch of at least 2*ceil(kb/64) unsigned (zeroed by the launcher on the stream).
+// scratch of at least G + G*G unsigned, G = ceil(kb/64) (zeroed by the launcher on the stream):
+// potrf_coop_sync_words(kb).
 template <class T>
 void launch_potrf_coop(T* tile, int ld, int kb, T* winv, int* info, int info_base, unsigned* sync,
                        hipStream_t stream);
+inline size_t potrf_coop_sync_words(int kb) {
+  const size_t g = (size_t) ((kb + kDiagBlock - 1) / kDiagBlock);
+  return g + g * g;
+}
 
 // ------------------------------------------------------------------------------------------
 // Layout kernels between the caller's column-major local array (staged on the device) and the

@@ -17,6 +17,9 @@
 // stores, every storing wave drains vmcnt, workgroup barrier, one relaxed agent atomic; the consumer
 // polls relaxed, then one agent-scope acquire fence, drained wait, workgroup barrier, plain loads.
 // Every spin is bounded.
+#include <cstdio>
+#include <cstdlib>
+
 #include "potrf_diag_core.hpp"
 
 namespace dlaf_mi355x {
@@ -102,6 +105,32 @@ __device__ __forceinline__ unsigned coop_wait(unsigned* word, unsigned target, u
   return r;
 }
 
+// all threads call: waits until every word of words[0 .. n) is non-zero (thread i polls word i); returns false
+// after the spin bound.  n <= kThreads.
+__device__ __forceinline__ bool coop_wait_all(unsigned* words, int n, unsigned* shared_slot) {
+  if (threadIdx.x == 0)
+    *shared_slot = 1u;
+  __syncthreads();
+  if ((int) threadIdx.x < n) {
+    long spins = 0;
+    while (__hip_atomic_load(&words[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+      __builtin_amdgcn_s_sleep(16);
+      if (++spins > kCoopSpinLimit) {
+        *shared_slot = 0u;
+        break;
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  const bool ok = *shared_slot != 0u;
+  __syncthreads();
+  return ok;
+}
+
 // global (rows x cols, ld) block -> LDS operand image [k = col][m = row], zero-filled to 64 x 64.
 // Two halves so that a caller can keep the 16 loads of a block in flight behind other work: the
 // kernel is latency-bound and, beside the bulk update, a global round trip costs several microseconds.
@@ -184,8 +213,11 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
   __shared__ int fail_col;
   __shared__ unsigned wait_slot;
   const int G = gridDim.x, s = blockIdx.x;
-  unsigned* flag = sync;     // flag[j] = 1: L_jj and inv(L_jj) are in memory;  kCoopFailed: not SPD
-  unsigned* cnt = sync + G;  // cnt[j]: strips whose X(.,j) is in memory
+  unsigned* flag = sync;       // flag[j] = 1: L_jj and inv(L_jj) are in memory;  kCoopFailed: not SPD
+  unsigned* xflag = sync + G;  // xflag[j * G + c] = 1: X(c, j) of strip c is in memory
+  // Every wait of strip s is on a strip with a LOWER block id (flag[j], j < s; xflag[j][c], c < s): with
+  // in-order dispatch the workgroups it depends on are already running or done, so the kernel makes progress
+  // whether or not all its workgroups are co-resident (a plain launch suffices).
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int g = lane >> 4, c = lane & 15;
@@ -226,9 +258,9 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
         if (m < rows_s)
           store_wt(&Asj[m + (long) n * ld], make_el<T>(xre[jt][v], C::CX ? xim[jt][v] : R(0)));
       }
-    coop_publish(&cnt[j], 1u, true);
-    const unsigned arrived = coop_wait(&cnt[j], (unsigned) (G - 1 - j), &wait_slot);
-    if (arrived == 0xFFFFFFFFu) {
+    coop_publish(&xflag[(long) j * G + s], 1u, false);
+    // the updates below read X(c, j) of the strips j < c < s (my own X_s is in LDS)
+    if (s - j - 1 > 0 && !coop_wait_all(&xflag[(long) j * G + j + 1], s - j - 1, &wait_slot)) {
       if (t == 0)
         atomicCAS(info, 0, kInfoSchedulingFailure);
       return;
@@ -350,13 +382,20 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
   }
 }
 
+static void fatal_device_config(const char* what) {
+  std::fprintf(stderr, "[dlaf_mi355x] %s\n", what);
+  std::abort();
+}
+
 template <class T>
 void launch_potrf_coop(T* tile, int ld, int kb, T* winv, int* info, int info_base, unsigned* sync,
                        hipStream_t stream) {
   if (kb <= 0)
     return;
   const int G = (kb + kCB - 1) / kCB;
-  (void) hipMemsetAsync(sync, 0, sizeof(unsigned) * 2 * (size_t) G, stream);
+  if (G > kThreads)
+    fatal_device_config("potrf_coop: more than 256 strips per tile");
+  (void) hipMemsetAsync(sync, 0, sizeof(unsigned) * ((size_t) G + (size_t) G * G), stream);
   hipLaunchKernelGGL((potrf_coop_kernel<T>), dim3((unsigned) G), dim3(kThreads), CoopCfg<T>::LDS_BYTES, stream, tile, ld,
                      kb, winv, info, info_base, sync);
 }

@@ -423,6 +423,10 @@ __global__ __launch_bounds__(kThreads, (TrsmRowsCfg<NW, ST>::WAVES_PER_SIMD)) vo
   }
 }
 
+}  // namespace dlaf_mi355x
+#include "trsm_rows_z.hpp"
+namespace dlaf_mi355x {
+
 template <class T>
 static bool aligned16(const void* ptr, long stride_elems) {
   return (reinterpret_cast<uintptr_t>(ptr) % 16 == 0) && ((stride_elems * (long) sizeof(T)) % 16 == 0);
@@ -457,6 +461,17 @@ void launch_trsm(const TrsmArgs<T>& a, hipStream_t stream) {
       return;
     }
   }
+  if constexpr (std::is_same<T, cdouble>::value) {
+    constexpr int NW = 128;
+    if (vec && !a.upper && trsm_rows_enabled() && a.nb % 64 == 0 && a.last_rows % 64 == 0 && a.n % NW == 0 &&
+        aligned16<T>(a.winv, 0)) {
+      const int spt = a.nb / 64;
+      const long grid = (long) (a.il1 - a.il0) * spt;
+      hipLaunchKernelGGL((trsm_rows_z_kernel<NW, 3>), dim3((unsigned) grid), dim3(kThreads),
+                         (TrsmRowsZCfg<NW, 3>::LDS_BYTES), stream, a, spt);
+      return;
+    }
+  }
   const int spt = (a.nb + Cfg::BM - 1) / Cfg::BM;
   const long grid = (long) (a.il1 - a.il0) * spt;
   auto go = [&](auto vtag, auto utag) {
@@ -483,6 +498,8 @@ static void trsm_init_one() {
 }
 
 void trsm_kernels_init() {
+  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_rows_z_kernel<128, 3>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, TrsmRowsZCfg<128, 3>::LDS_BYTES);
   (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_rows_kernel<256, 2>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, TrsmRowsCfg<256, 2>::LDS_BYTES);
   trsm_init_one<float>();

@@ -68,7 +68,7 @@ struct UpdateMap {
 };
 
 // One work item = one BM x BN block of one tile.  Returns early for blocks outside the domain.
-template <class T, bool VEC>
+template <class T, bool VEC, bool UTAIL = false>
 __device__ __forceinline__ void update_block(const UpdateArgs<T>& p, const UpdateMap& mp, long w,
                                              real_t<T>* __restrict__ lds) {
   using Cfg = typename UpdateCfg<T>::type;
@@ -148,6 +148,19 @@ __device__ __forceinline__ void update_block(const UpdateArgs<T>& p, const Updat
     A2 = p.a2 + aoff + m0 - (long) K1 * p.lda;
     B2 -= (long) K1 * ldb;
   }
+#ifdef DLAF_DBG_STRIP_PACKED
+  // tuning aid (tools/update_bench.hip): operands read as if every BM-row strip of a tile were stored
+  // contiguously (k-major, leading dimension BM): one sequential 1 MiB stream per strip instead of 1 KiB pieces
+  // 8 KiB apart.  Timing only -- the values are whatever lies there.
+  const long lda_x = Cfg::BM, ldb_x = Cfg::BN;
+  A = p.a + aoff + (long) (m0 / Cfg::BM) * Cfg::BM * p.nb;
+  B = (diag ? p.a + aoff : p.b + boff) + (long) (n0 / Cfg::BN) * Cfg::BN * p.nb;
+#define DLAF_LDA_X lda_x
+#define DLAF_LDB_X ldb_x
+#else
+#define DLAF_LDA_X p.lda
+#define DLAF_LDB_X ldb
+#endif
 #ifdef DLAF_DBG_SAME_STRIPS
   A = p.a;  // tuning aid (tools/update_bench.hip): every block streams the same two strips = perfect L2 locality
   B = p.b;
@@ -158,7 +171,7 @@ __device__ __forceinline__ void update_block(const UpdateArgs<T>& p, const Updat
   Acc<Cfg> acc;
   acc.clear();
   if (full)
-    gemm_nt_block<Cfg, T, VEC, false>(A, p.lda, mrows, B, ldb, ncols, p.K, lds, acc, K1, A2, B2);
+    gemm_nt_block<Cfg, T, VEC, false, UTAIL>(A, DLAF_LDA_X, mrows, B, DLAF_LDB_X, ncols, p.K, lds, acc, K1, A2, B2);
   else
     gemm_nt_block<Cfg, T, false, true>(A, p.lda, mrows, B, ldb, ncols, p.K, lds, acc, K1, A2, B2);
 
@@ -320,7 +333,7 @@ __global__ __launch_bounds__(UpdateCfg<T>::type::THREADS, UpdateCfg<T>::min_wave
     __syncthreads();
     if (i >= per_q)
       break;
-    update_block<T, VEC>(p, mp, (long) q * per_q + i, lds);
+    update_block<T, VEC, ROLE == 0>(p, mp, (long) q * per_q + i, lds);
   }
 }
 

@@ -253,7 +253,12 @@ __device__ __forceinline__ void stage_glds_one(const T* __restrict__ A, long lda
 // Two-segment form: columns k >= K1 of both operands come from A2 / B2 (same leading dimensions): the
 // product of two panels applied in one pass (K = K1 + K2, one epilogue), or the two products of a her2k.
 // A2 / B2 are passed already shifted back by K1 columns, K1 is a multiple of BK; K1 >= K: one segment.
-template <class Cfg, class T, bool VEC, bool EDGE>
+// UTAIL (direct-to-LDS path): the K loop issues loads in EVERY iteration -- past the end the last slab is fetched
+// again into the ring slot consumed an iteration ago, never read, drained after the loop -- so the loop body has
+// no branch around the loads and one wait count.  Measured on the persistent bulk launches (fp64, 480 workgroups):
+// 65.7 -> 67.0 TFlop/s at K = 1024, 66.2 -> 67.4 at K = 2048; on one-block-per-workgroup launches it costs 8 %
+// (the drain delays the epilogue), so only the bulk instantiation of the update kernel asks for it.
+template <class Cfg, class T, bool VEC, bool EDGE, bool UTAIL = false>
 __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda, int mrows,
                                               const T* __restrict__ B, long ldb, int ncols, int K,
                                               typename Cfg::R* __restrict__ lds, Acc<Cfg>& acc, int K1 = 1 << 30,
@@ -285,7 +290,7 @@ __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda,
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #ifndef DLAF_GLDS_INTERLEAVE
-#define DLAF_GLDS_INTERLEAVE 0
+#define DLAF_GLDS_INTERLEAVE 1
 #endif
 #if DLAF_GLDS_INTERLEAVE
     int cur_i = 0, nxt_i = ST - 1;
@@ -293,9 +298,10 @@ __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda,
     // tuning aid (tools/update_bench.hip): where a K-loop iteration spends its cycles, per wave
     unsigned long long st_issue = 0, st_mma = 0, st_vm = 0, st_bar = 0;
 #endif
-    // The loads of slab kt+ST-1 are issued inside the MFMA stream of slab kt, one share per 4-deep step, and
-    // without a branch: past the end the LAST slab is fetched again into the ring slot that was consumed an
-    // iteration ago (never read again; drained after the loop).  The wait count is then the same every time.
+    // The loads of slab kt+ST-1 are issued INSIDE the MFMA stream of slab kt, one instruction per group of TM
+    // MFMAs over the first groups of the slab, instead of as a block of LPS instructions at the head of the
+    // iteration.  Measured (tools/run_ab_interleave.sh, fp64): persistent launches 65.7 -> 67.0 TFlop/s at
+    // K = 1024, 66.2 -> 67.4 at K = 2048, 60.4 -> 61.5 at nb = 512.  The last ST-1 iterations load nothing.
     constexpr bool SPLIT = !Cfg::CXI && LPS <= (Cfg::BK / 4) * Cfg::TN && LPS <= 16;
     for (int kt = 0; kt < nk; ++kt) {
 #ifdef DLAF_DBG_STAMPS
@@ -304,8 +310,11 @@ __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda,
       R* cur = lds + cur_i * Cfg::BUF_ELEMS;
 #ifdef DLAF_DBG_SKIP_GLOBAL
       cur = lds;
-      mma_slab<Cfg>(cur, cur + Cfg::A_ELEMS, acc, wm, wn, lane);
+      const bool load = false;
 #else
+      const bool load = UTAIL || (kt + ST - 1 < nk);
+#endif
+      // (one copy of the MFMA stream: `load` only guards the single instructions, a scalar branch each)
       const int kn = min(kt + ST - 1, nk - 1) * Cfg::BK;
       const T* An = kn < K1 ? A : A2;
       const T* Bn = kn < K1 ? B : B2;
@@ -313,27 +322,31 @@ __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda,
       if constexpr (SPLIT) {
         mma_slab<Cfg>(cur, cur + Cfg::A_ELEMS, acc, wm, wn, lane, [&](int p) {
           // (p is a compile-time constant after unrolling: the chain folds to the one instruction of group p)
-#define DLAF_GLDS_AT(I)                                                                   \
-  if (p == I) {                                                                         \
-    if constexpr (I < LPS)                                                              \
-      stage_glds_one<Cfg, T, (I < LPS ? I : 0)>(An, lda, Bn, ldb, kn, nbuf, wave, lane); \
+#define DLAF_GLDS_AT(I)                                                                     \
+  if (p == I) {                                                                           \
+    if constexpr (I < LPS)                                                                \
+      if (load)                                                                           \
+        stage_glds_one<Cfg, T, (I < LPS ? I : 0)>(An, lda, Bn, ldb, kn, nbuf, wave, lane); \
   }
-          DLAF_GLDS_AT(0) DLAF_GLDS_AT(1) DLAF_GLDS_AT(2) DLAF_GLDS_AT(3) DLAF_GLDS_AT(4) DLAF_GLDS_AT(5) DLAF_GLDS_AT(6)
-          DLAF_GLDS_AT(7) DLAF_GLDS_AT(8) DLAF_GLDS_AT(9) DLAF_GLDS_AT(10) DLAF_GLDS_AT(11) DLAF_GLDS_AT(12)
-          DLAF_GLDS_AT(13) DLAF_GLDS_AT(14) DLAF_GLDS_AT(15)
+          DLAF_GLDS_AT(0) DLAF_GLDS_AT(1) DLAF_GLDS_AT(2) DLAF_GLDS_AT(3) DLAF_GLDS_AT(4) DLAF_GLDS_AT(5)
+          DLAF_GLDS_AT(6) DLAF_GLDS_AT(7) DLAF_GLDS_AT(8) DLAF_GLDS_AT(9) DLAF_GLDS_AT(10) DLAF_GLDS_AT(11)
+          DLAF_GLDS_AT(12) DLAF_GLDS_AT(13) DLAF_GLDS_AT(14) DLAF_GLDS_AT(15)
 #undef DLAF_GLDS_AT
         });
       }
       else {
-        stage_glds<Cfg, T>(An, lda, Bn, ldb, kn, nbuf, wave, lane);
+        if (load)
+          stage_glds<Cfg, T>(An, lda, Bn, ldb, kn, nbuf, wave, lane);
         mma_slab<Cfg>(cur, cur + Cfg::A_ELEMS, acc, wm, wn, lane);
       }
-#endif
+      // slab kt+1 landed?  still in flight afterwards: the loads of slabs kt+2 .. kt+ST-1 (none in the tail)
+      if (load)
+        __builtin_amdgcn_s_waitcnt(0x0070 | ((LPS * (ST - 2)) & 0xF) | ((((LPS * (ST - 2)) >> 4) & 0x3) << 14));
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef DLAF_DBG_STAMPS
       const unsigned long long t2 = __builtin_amdgcn_s_memtime();
 #endif
-      // slab kt+1 landed?  still in flight afterwards: the loads of slabs kt+2 .. kt+ST-1
-      __builtin_amdgcn_s_waitcnt(0x0070 | ((LPS * (ST - 2)) & 0xF) | ((((LPS * (ST - 2)) >> 4) & 0x3) << 14));
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifdef DLAF_DBG_STAMPS
       const unsigned long long t3 = __builtin_amdgcn_s_memtime();
@@ -348,10 +361,12 @@ __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda,
       cur_i = (cur_i + 1 == ST) ? 0 : cur_i + 1;
       nxt_i = (nxt_i + 1 == ST) ? 0 : nxt_i + 1;
     }
-    // the re-fetched slabs of the last ST-1 iterations: nobody reads them, but they must have landed before the
-    // caller reuses the ring
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if constexpr (UTAIL) {
+      // the re-fetched slabs of the last ST-1 iterations: nobody reads them, but they must have landed (in every
+      // wave) before the caller reuses the ring
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
 #ifdef DLAF_DBG_STAMPS
     if (lane == 0) {
       atomicAdd(&g_dbg_stamps[0], st_issue);

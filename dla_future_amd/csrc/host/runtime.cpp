@@ -222,7 +222,8 @@ void DeviceMatrix<T>::create(Grid* g, char uplo_, long n_, int nb_, int isrc, in
   }
   DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&info), sizeof(int)));
   DLAF_HIP_CHECK(hipMemset(info, 0, sizeof(int)));
-  DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&coop_sync), sizeof(unsigned) * (2 * (size_t) (nb / kDiagBlock + 2) + 8)));
+  // [8 dequeue heads of the persistent update launches | flags of the cooperative tile POTRF]
+  DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&coop_sync), sizeof(unsigned) * (8 + potrf_coop_sync_words(nb))));
   DLAF_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&info_host), sizeof(int), hipHostMallocDefault));
   *info_host = 0;
 
@@ -753,8 +754,7 @@ void DeviceMatrix<T>::factorize_async() {
     update_work(il0, il1, j0, j1, st.kb, fl, by);
     const int pk = kind < 0 ? role : kind;
     prof_begin(pk, s);
-    launch_update(ua, s, role, reserve > 0 ? std::max<long>(8, bulk_slots - reserve) : 0,
-                  coop_sync + 2 * (nb / kDiagBlock + 2));
+    launch_update(ua, s, role, reserve > 0 ? std::max<long>(8, bulk_slots - reserve) : 0, coop_sync);
     prof_end(pk, s, fl, by);
   };
 
@@ -802,7 +802,7 @@ void DeviceMatrix<T>::factorize_async() {
     const int kb = rows.tile_extent(k);
     const double cxf = TypeInfo<T>::is_complex ? 4.0 : 1.0;
     prof_begin(3, s_panel);
-    potrf_tile(tile(rows.local_of(k), cols.local_of(k)), nb, kb, winv_of(k), info, (int) (k * nb), coop_sync, s_panel);
+    potrf_tile(tile(rows.local_of(k), cols.local_of(k)), nb, kb, winv_of(k), info, (int) (k * nb), coop_sync + 8, s_panel);
     prof_end(3, s_panel, cxf * (double) kb * kb * kb / 3.0, (double) kb * kb * sizeof(T));
   };
 
@@ -1517,7 +1517,7 @@ int tile_potrf(char uplo, int n, T* a, int lda) {
   hipStream_t s = nullptr;
   DevBuf<T> da((size_t) n * n), tmp((size_t) n * n), w((size_t) ((n + kDiagBlock - 1) / kDiagBlock) * kDiagBlock * kDiagBlock);
   DevBuf<int> info(1);
-  DevBuf<unsigned> sync((size_t) 2 * (n / kDiagBlock + 2));
+  DevBuf<unsigned> sync(potrf_coop_sync_words(n));
   DLAF_HIP_CHECK(hipMemsetAsync(info.p, 0, sizeof(int), s));
   // tmp keeps the caller's image (host orientation); da the device orientation
   DLAF_HIP_CHECK(hipMemcpy2DAsync(tmp.p, (size_t) n * sizeof(T), a, (size_t) lda * sizeof(T), (size_t) n * sizeof(T),

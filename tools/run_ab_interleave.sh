@@ -4,10 +4,11 @@
 cd ${GRAFT_REPO_ROOT:-.}
 OUT=${1:-gpurun_out/ab_interleave}
 mkdir -p $OUT
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include tools/update_bench.hip -o /tmp/ub_old
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -DDLAF_GLDS_INTERLEAVE=0 tools/update_bench.hip -o /tmp/ub_old
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -DDLAF_GLDS_INTERLEAVE=1 tools/update_bench.hip -o /tmp/ub_new
-for round in 1 2; do
-  for v in old new; do
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -DDLAF_GLDS_INTERLEAVE=1 -DDLAF_DBG_STRIP_PACKED tools/update_bench.hip -o /tmp/ub_packed
+for round in ${AB_ROUNDS:-1 2}; do
+  for v in ${AB_VARIANTS:-old new packed}; do
     for args in "48 1024 3 0" "48 1024 3 480" "24 2048 3 480" "64 512 3 480"; do
       echo "== $v $args (round $round)" | tee -a $OUT/timing.txt
       /tmp/ub_$v $args | grep TFlop | tail -2 | tee -a $OUT/timing.txt
