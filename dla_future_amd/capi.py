@@ -80,6 +80,7 @@ SIGNATURES = {
     "dlaf_mi355x_cholesky_wait": (_i, [_vp]),
     "dlaf_mi355x_cholesky_factorization_device": (_i, [_vp]),
     "dlaf_mi355x_cholesky_residual": (_i, [_vp, _vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "dlaf_mi355x_matrix_trsm_profile": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dlaf_mi355x_matrix_profile": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_long),
                                         C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dlaf_mi355x_triangular_solver_s": (_i, [_i, _ch, _ch, _ch, _ch, _vp, _vp, DLAFDescriptor, _vp, DLAFDescriptor]),

@@ -333,6 +333,13 @@ class DeviceMatrix:
                                          C.byref(by))
         return {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
 
+    def trsm_profile(self, reps: int = 5) -> dict:
+        """The panel TRSM of step 0 alone on the device (after factorize(); one-process grids): HIP-event time per
+        launch and the algorithmic work of one launch."""
+        ms, fl, by = C.c_double(), C.c_double(), C.c_double()
+        lib().dlaf_mi355x_matrix_trsm_profile(self._h, reps, C.byref(ms), C.byref(fl), C.byref(by))
+        return {"ms": ms.value, "flops": fl.value, "bytes": by.value}
+
     def close(self) -> None:
         if self._h:
             lib().dlaf_mi355x_matrix_destroy(self._h)

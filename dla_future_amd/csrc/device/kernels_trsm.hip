@@ -369,20 +369,37 @@ __global__ __launch_bounds__(kThreads, (TrsmRowsCfg<NW, ST>::WAVES_PER_SIMD)) vo
 #pragma unroll
       for (int t4 = 0; t4 < 4; ++t4)
         X[t4] = acc_t{0, 0, 0, 0};
+      // k outermost: the X tiles of both column groups advance together (four independent accumulator chains
+      // while h = 0); the fragment reads of four k steps are issued as one batch ahead of their MFMAs
 #pragma unroll
-      for (int qp = 0; qp < 2; ++qp)
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int h = 0; h <= qp; ++h)
+        for (int b = 0; b < 2; ++b) {
+          d2 wf[2][4];
 #pragma unroll
-          for (int b = 0; b < 2; ++b)
+          for (int v = 0; v < 4; ++v) {
+            // accumulator register v of tile 2h+b holds column k of the sub-block: read W[:, k]
+            const int k = 32 * h + 2 * (g + 4 * v) + b;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-              // accumulator register v of tile 2h+b holds column k of the sub-block: read W[:, k]
-              const int k = 32 * h + 2 * (g + 4 * v) + b;
-              const d2 wf = *reinterpret_cast<const d2*>(&Wbuf[k * kDiagBlock + 32 * qp + 2 * c]);
-              X[2 * qp] = Mma<double>::mma(wf[0], Breg[2 * h + b][v], X[2 * qp]);
-              X[2 * qp + 1] = Mma<double>::mma(wf[1], Breg[2 * h + b][v], X[2 * qp + 1]);
+            for (int qp = h; qp < 2; ++qp)
+              wf[qp][v] = *reinterpret_cast<const d2*>(&Wbuf[k * kDiagBlock + 32 * qp + 2 * c]);
+          }
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int qp = h; qp < 2; ++qp) {
+              X[2 * qp] = Mma<double>::mma(wf[qp][v][0], Breg[2 * h + b][v], X[2 * qp]);
+              X[2 * qp + 1] = Mma<double>::mma(wf[qp][v][1], Breg[2 * h + b][v], X[2 * qp + 1]);
             }
+          if (h == 0) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // the batch of LDS reads ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);  // ... then its MFMAs
+          }
+          else {
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+          }
+        }
 #pragma unroll
       for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
@@ -410,11 +427,29 @@ __global__ __launch_bounds__(kThreads, (TrsmRowsCfg<NW, ST>::WAVES_PER_SIMD)) vo
           // stage columns 8uu + 2g + b of the sub-block <-> accumulator register uu & 3 of tile 2 (uu >> 2) + b
           const double xf = X[2 * (uu >> 2) + b][uu & 3];
           const int kk = 2 * g + b;
+          // fragment reads of the step as one batch ahead of its MFMAs
+          d2 lf[C::NT / 2];
+#pragma unroll
+          for (int q = qmin; q < C::NT / 2; ++q)
+            lf[q] = *reinterpret_cast<const d2*>(&buf[kk * NW + 32 * q + 2 * c]);
 #pragma unroll
           for (int q = qmin; q < C::NT / 2; ++q) {
-            const d2 lf = *reinterpret_cast<const d2*>(&buf[kk * NW + 32 * q + 2 * c]);
-            S[2 * q] = Mma<double>::mma(lf[0], xf, S[2 * q]);
-            S[2 * q + 1] = Mma<double>::mma(lf[1], xf, S[2 * q + 1]);
+            S[2 * q] = Mma<double>::mma(lf[q][0], xf, S[2 * q]);
+            S[2 * q + 1] = Mma<double>::mma(lf[q][1], xf, S[2 * q + 1]);
+          }
+          if constexpr (NW == 256) {
+            if (s == 0) {
+              __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+            }
+            else if (s == 1) {
+              __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            }
+            else {
+              __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
           }
         }
         ring_step_end(i);

@@ -567,6 +567,10 @@ int dlaf_mi355x_generalized_to_standard_device(dlaf_mi355x_matrix_t a, dlaf_mi35
   WITH_MATRIX(a, return gen_to_std_device(M, static_cast<DeviceMatrix<DT>&>(*l->m));)
 }
 
+int dlaf_mi355x_matrix_trsm_profile(dlaf_mi355x_matrix_t h, int reps, double* ms, double* flops, double* bytes) noexcept {
+  WITH_MATRIX(h, const double t = M.trsm_profile(reps, flops, bytes); if (ms) *ms = t; return 0;)
+}
+
 int dlaf_mi355x_matrix_profile(dlaf_mi355x_matrix_t h, int kind, double* ms, long* launches, double* flops,
                                double* bytes) noexcept {
   if (kind < 0 || kind > 3)

@@ -1403,6 +1403,69 @@ bool DeviceMatrix<T>::fetch_tile(long gi, long gj, T* host, long ld) {
 }
 
 template <class T>
+double DeviceMatrix<T>::trsm_profile(int reps, double* flops, double* bytes) {
+  if (flops)
+    *flops = 0;
+  if (bytes)
+    *bytes = 0;
+  if (grid->nranks != 1 || nt < 2 || reps < 1)
+    return 0.0;
+  const long ntiles = ltr - 1;
+  T* scratch = dev_alloc<T>((size_t) ntiles * tile_elems);
+  T* w = dev_alloc<T>(winv_elems());
+  hipStream_t s = s_low;
+  DLAF_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int), s));
+  launch_invert_diag_blocks(tile(0, 0), nb, nb, w, info, s, false, false);
+  TrsmArgs<T> ta;
+  ta.b = scratch;
+  ta.b_ts = (long) tile_elems;
+  ta.ldb = nb;
+  ta.il0 = 1;
+  ta.il1 = (int) ltr;
+  ta.pr = 1;
+  ta.ri = 0;
+  ta.nb = nb;
+  ta.nt = (int) nt;
+  ta.last_rows = rows.last_extent();
+  ta.l = tile(0, 0);
+  ta.ldl = nb;
+  ta.winv = w;
+  ta.n = nb;
+  ta.info = info;
+  hipEvent_t e0, e1;
+  DLAF_HIP_CHECK(hipEventCreate(&e0));
+  DLAF_HIP_CHECK(hipEventCreate(&e1));
+  float total = 0;
+  for (int r = -1; r < reps; ++r) {  // r = -1: warm-up
+    // a fresh copy of the solved panel each time (X L^-H applied again and again would shrink to nothing)
+    DLAF_HIP_CHECK(hipMemcpyAsync(scratch, tile(1, 0), (size_t) ntiles * tile_elems * sizeof(T), hipMemcpyDeviceToDevice, s));
+    DLAF_HIP_CHECK(hipEventRecord(e0, s));
+    launch_trsm(ta, s);
+    DLAF_HIP_CHECK(hipEventRecord(e1, s));
+    DLAF_HIP_CHECK(hipStreamSynchronize(s));
+    float ms = 0;
+    DLAF_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (r >= 0)
+      total += ms;
+  }
+  (void) hipEventDestroy(e0);
+  (void) hipEventDestroy(e1);
+  DLAF_HIP_CHECK(hipFree(scratch));
+  DLAF_HIP_CHECK(hipFree(w));
+  double fl = 0, by = 0;
+  for (long il = 1; il < ltr; ++il) {
+    const double mi = rows.tile_extent(rows.global_of(il));
+    fl += (TypeInfo<T>::is_complex ? 4.0 : 1.0) * (double) nb * nb * mi;
+    by += (0.5 * nb * nb + 2.0 * mi * nb) * sizeof(T);
+  }
+  if (flops)
+    *flops = fl;
+  if (bytes)
+    *bytes = by;
+  return (double) total / reps;
+}
+
+template <class T>
 int DeviceMatrix<T>::factorize() {
   factorize_async();
   return wait();

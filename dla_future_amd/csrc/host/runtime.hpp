@@ -188,6 +188,12 @@ struct DeviceMatrix : MatrixBase {
   // one tile of the device copy (global tile indices of the caller's matrix, not of the transposed view)
   // to / from a dense host array; returns false when this rank does not own the tile
   bool fetch_tile(long gi, long gj, T* host, long ld);
+  // Measurement hook (bench.py): the panel TRSM of step 0 ALONE on the device -- on a copy of the factored first
+  // tile column (local rows below the diagonal) with the factored diagonal tile, `reps` launches between two HIP
+  // events.  In the factorization the panel solves run beside the bulk update on a few free workgroup slots, so
+  // their in-situ durations say nothing about the kernel; this does.  One-process grids, after factorize().
+  // Returns the average ms per launch; *flops / *bytes: algorithmic work of one launch.
+  double trsm_profile(int reps, double* flops, double* bytes);
 };
 
 // single-tile operations with host operands (tests of the tile kernels through the C ABI)

@@ -95,6 +95,12 @@ DLAF_EXTERN_C int dlaf_mi355x_cholesky_residual(dlaf_mi355x_matrix_t original, d
  * ALGORITHMIC work of those launches (BASELINE.md roofline table).  Call after *_wait. */
 DLAF_EXTERN_C int dlaf_mi355x_matrix_profile(dlaf_mi355x_matrix_t m, int kind, double* ms, long* launches,
                                              double* flops, double* bytes) DLAF_NOEXCEPT;
+/* The panel TRSM of step 0 ALONE on the device: `reps` launches on a copy of the factored first tile column with
+ * the factored diagonal tile, timed with HIP events (in the factorization the panel solves run beside the bulk
+ * update on a few free workgroup slots; their in-situ durations do not describe the kernel).  One-process grids,
+ * after a factorization.  *ms = average per launch, *flops / *bytes = algorithmic work of one launch. */
+DLAF_EXTERN_C int dlaf_mi355x_matrix_trsm_profile(dlaf_mi355x_matrix_t m, int reps, double* ms, double* flops,
+                                                  double* bytes) DLAF_NOEXCEPT;
 /* barrier over the matrix's grid (RCCL all-reduce / host callback) */
 DLAF_EXTERN_C int dlaf_mi355x_grid_barrier(int context) DLAF_NOEXCEPT;
 /* Collective communication self-test of a grid (what test/unit/communication/test_broadcast*.cpp do for
