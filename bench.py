@@ -254,6 +254,9 @@ def main():
                            "alone_launch_ms": round(trsm_alone["ms"], 4) if trsm_alone else None,
                            "in_situ_TFlops": round(trsm["flops"] / max(trsm["ms"], 1e-9) / 1e9, 3),
                            "launches": trsm["launches"], "in_situ_avg_launch_ms": round(trsm["ms"] / max(1, trsm["launches"]), 4)},
+            "update_lookahead": {"launches": prof["update_lookahead"]["launches"],
+                                 "total_ms_per_step": round(prof["update_lookahead"]["ms"] / max(1, args.steps), 3),
+                                 "achieved_TFlops": round(prof["update_lookahead"]["flops"] / max(prof["update_lookahead"]["ms"], 1e-9) / 1e9, 3)},
             "potrf_tile": {"launches": prof["potrf_tile"]["launches"],
                            "avg_ms": round(prof["potrf_tile"]["ms"] / max(1, prof["potrf_tile"]["launches"]), 4)},
             "setup": {"generate_s": round(t_gen, 2), "upload_s": round(t_up, 2)},

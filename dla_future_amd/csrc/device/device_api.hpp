@@ -61,7 +61,7 @@ struct UpdateArgs {
 };
 // role: 0 trailing bulk, 1 lookahead column, 2 in-tile POTRF update / single-tile entries, 3 residual checker
 // and triangular solver (same code, separate kernel names, so that profiles of the factorization stay clean)
-// max_blocks > 0 (with counters = 8 device words of scratch): launch at most that many workgroups and
+// max_blocks > 0 (with counters = 16 device words of scratch): launch at most that many workgroups and
 // let them pull work items (persistent form): what is left of the GPU stays free for kernels that
 // must run beside the update.
 template <class T>

@@ -222,8 +222,8 @@ void DeviceMatrix<T>::create(Grid* g, char uplo_, long n_, int nb_, int isrc, in
   }
   DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&info), sizeof(int)));
   DLAF_HIP_CHECK(hipMemset(info, 0, sizeof(int)));
-  // [8 dequeue heads of the persistent update launches | flags of the cooperative tile POTRF]
-  DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&coop_sync), sizeof(unsigned) * (8 + potrf_coop_sync_words(nb))));
+  // [8 dequeue heads + 8 pacing counters of the persistent update launches | flags of the cooperative tile POTRF]
+  DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&coop_sync), sizeof(unsigned) * (16 + potrf_coop_sync_words(nb))));
   DLAF_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&info_host), sizeof(int), hipHostMallocDefault));
   *info_host = 0;
 
@@ -802,7 +802,7 @@ void DeviceMatrix<T>::factorize_async() {
     const int kb = rows.tile_extent(k);
     const double cxf = TypeInfo<T>::is_complex ? 4.0 : 1.0;
     prof_begin(3, s_panel);
-    potrf_tile(tile(rows.local_of(k), cols.local_of(k)), nb, kb, winv_of(k), info, (int) (k * nb), coop_sync + 8, s_panel);
+    potrf_tile(tile(rows.local_of(k), cols.local_of(k)), nb, kb, winv_of(k), info, (int) (k * nb), coop_sync + 16, s_panel);
     prof_end(3, s_panel, cxf * (double) kb * kb * kb / 3.0, (double) kb * kb * sizeof(T));
   };
 
@@ -864,10 +864,11 @@ void DeviceMatrix<T>::factorize_async() {
   Step prev;  // step k-1, whose bulk update is still to be issued (in part or in full)
 
   if (pairs) {
-    // s_main : LA(p-1) . rest(p-1) ............................................ LA(p) . rest(p) ...
-    // s_panel:           POTRF(k) . TRSM(k) . U1(k -> col k+1) . POTRF(k+1) . TRSM(k+1)
-    // pair p = steps (k, k+1); LA(p) = the two-panel update of tile columns k+2, k+3 (what the next pair's
-    // panels need), rest(p) = columns >= k+4 as one persistent launch that leaves `sidecar_slots` free.
+    // s_main : LA(p-1) . restA(p-1) ........ U1(k -> col k+1) . restB(p-1) ................. LA(p) . restA(p) ...
+    // s_panel:           POTRF(k) . TRSM(k) ^                    POTRF(k+1) . TRSM(k+1) ^
+    // pair p = steps (k, k+1); LA(p) = the two-panel update of tile columns k+2, k+3 (what the next pair's panels
+    // need), rest(p) = columns >= k+4 in two persistent launches that leave `sidecar_slots` free for the panel
+    // kernels beside them, U1 = column k+1 under panel k alone on s_main between the two.
     auto single = [&](long k) {  // the one-panel step of step k (operands of U1)
       Step st;
       st.valid = true;
@@ -878,19 +879,20 @@ void DeviceMatrix<T>::factorize_async() {
       st.b_ts = (long) tile_elems;
       return st;
     };
-    // Workgroup slots rest(p-1) leaves free for the panel work of pair p running beside it: too few and the
-    // panel chain (2 POTRF + 2 TRSM, throughput ~ slots) outlasts the bulk, too many and the bulk loses that
-    // share of the GPU for its whole duration.  Chosen per pair from a two-line cost model (rates measured on
-    // MI355X); DLAF_MI355X_SIDECAR_SLOTS fixes it.
-    // (measured: the fixed reservation of 32 slots beat this model at N=32768 nb=512 -- 57.2 vs 54.8 TFlop/s --
-    // and tied it at N=65536 nb=1024, so the model is opt-in: DLAF_MI355X_ADAPTIVE_SLOTS=1)
-    const bool slots_fixed = std::getenv("DLAF_MI355X_ADAPTIVE_SLOTS") == nullptr;
+    // Workgroup slots rest(p-1) leaves free for the panel work of pair p running beside it.  32 (the POTRF's
+    // strips plus a few TRSM workgroups) is the measured optimum while the bulk outlasts the panel chain (16 ->
+    // 65.5, 32 -> 67.4, 48 -> 66.8 TFlop/s at N=65536 nb=1024).  Towards the end of the factorization the bulk
+    // of a pair is shorter than the chain 2 POTRF + 2 TRSM beside it; there the reservation grows until the two
+    // balance (the TRSM's throughput is proportional to the slots it finds).  Rates: in-situ measurements on
+    // MI355X.  DLAF_MI355X_SIDECAR_SLOTS fixes the reservation, DLAF_MI355X_LATE_BOOST=0 keeps it at its default.
+    const bool slots_fixed = std::getenv("DLAF_MI355X_SIDECAR_SLOTS") != nullptr ||
+                             (std::getenv("DLAF_MI355X_LATE_BOOST") && std::atoi(std::getenv("DLAF_MI355X_LATE_BOOST")) == 0);
     auto pair_slots = [&](long k, const Step& bulk) -> long {
       if (slots_fixed || !bulk.valid || bulk.rest0 >= ltc)
         return sidecar_slots;
       const bool cxt = TypeInfo<T>::is_complex, dbl = sizeof(real_t<T>) == 8;
-      const double r_bulk = (dbl ? 66e12 : 118e12) * (cxt && !dbl ? 1.1 : 1.0);
-      const double r_trsm = dbl ? (cxt ? 23e12 : 50e12) : 60e12;
+      const double r_bulk = dbl ? 66e12 : 118e12;
+      const double r_trsm_slot = (dbl ? 5e12 : 8e12) / 32.0;  // per free slot, beside the bulk
       double fl_b = 0, by;
       for (long jl = bulk.rest0; jl < ltc; ++jl) {
         double f;
@@ -901,15 +903,19 @@ void DeviceMatrix<T>::factorize_async() {
       const double below = (double) std::max<long>(0, n - (k + 1) * (long) nb) + (double) std::max<long>(0, n - (k + 2) * (long) nb);
       const double fl_t = cxf * (double) nb * nb * below;
       const double nblk = (double) nb / kDiagBlock;
-      const double t_potrf = 2.0 * nblk * nblk * 13.7e-6 * (cxt ? 2.0 : 1.0);
-      const long lo = std::max<long>(potrf_slots, 8);
-      long best = std::max(lo, sidecar_slots);
-      double best_t = 1e30;
-      for (long cand : {8L, 16L, 24L, 32L, 48L, 64L, 96L, 128L, 192L, 256L}) {
-        if (cand < lo || cand >= bulk_slots)
+      const double t_potrf = 2.0 * nblk * nblk * 11.3e-6 * (cxt ? 2.0 : 1.0);  // 2.9 ms per 1024-tile beside the bulk
+      auto t_of = [&](long sl) {
+        const double share = (double) sl / (double) bulk_slots;
+        return std::max(fl_b / (r_bulk * (1.0 - share)), t_potrf + fl_t / (r_trsm_slot * (double) sl));
+      };
+      long best = sidecar_slots;
+      double best_t = t_of(best);
+      if (fl_b / (r_bulk * (1.0 - (double) best / (double) bulk_slots)) >= best_t)
+        return best;  // the bulk is the longer of the two: nothing to gain
+      for (long cand : {48L, 64L, 96L, 128L, 192L, 256L}) {
+        if (cand <= sidecar_slots || cand * 2 > bulk_slots)
           continue;
-        const double share = (double) cand / (double) bulk_slots;
-        const double t = std::max(fl_b / (r_bulk * (1.0 - share)), t_potrf + fl_t / (r_trsm * share));
+        const double t = t_of(cand);
         if (t < best_t) {
           best_t = t;
           best = cand;
@@ -917,6 +923,12 @@ void DeviceMatrix<T>::factorize_async() {
       }
       return best;
     };
+    // share of rest(p-1) issued BEFORE U1 on s_main (it runs beside POTRF(k) + TRSM(k))
+    const double split_frac = [&] {
+      if (const char* e = std::getenv("DLAF_MI355X_PAIR_SPLIT"))
+        return std::atof(e);
+      return 0.3;
+    }();
     for (long k = 0; k < nt; k += 2) {
       if (tr)
         tr->mark(k);
@@ -924,21 +936,68 @@ void DeviceMatrix<T>::factorize_async() {
         DLAF_HIP_CHECK(hipStreamWaitEvent(s_panel, ev_high[k - 2], 0));  // LA(p-1): columns k, k+1 are final
       potrf(k);
       const bool second = k + 1 < nt;       // the pair has a second step
+      const bool more = k + 2 < nt;         // something trails the pair
       if (second) {
         trsm(k + 1, ltr, k, tile(k, k), winv_of(k), rows.tile_extent(k), s_panel);
         DLAF_HIP_CHECK(hipEventRecord(ev_panel[k], s_panel));
         panels_issued.store(k, std::memory_order_release);
-        update(single(k), k + 1, k + 2, s_panel, 1, 0);
+      }
+      // U1 (column k+1 under panel k) is on the chain POTRF(k) . TRSM(k) . U1 . POTRF(k+1) . TRSM(k+1).  Two places
+      // for it: (a) on s_panel beside the bulk, on the few slots the bulk leaves free -- ~16 ms instead of 1 ms at
+      // N=65536 nb=1024, harmless while the bulk of the pair outlasts the chain anyway; (b) alone on s_main between
+      // two halves of the bulk -- the chain shrinks to what the GPU can do, at the price of a second ramp-down of
+      // the persistent bulk launch.  (a) while the bulk is the longer of the two, (b) towards the end.
+      long splitA = prev.rest0;
+      const long slots = pair_slots(k, prev);
+      bool u1_on_main = false;
+      if (prev.valid && prev.rest0 < ltc && second) {
+        double total = 0, by;
+        std::vector<double> colfl((size_t) (ltc - prev.rest0));
+        for (long jl = prev.rest0; jl < ltc; ++jl) {
+          double f;
+          update_work(std::max(prev.il_n, rows.next_local(cols.global_of(jl))), ltr, jl, jl + 1, prev.kb, f, by);
+          colfl[(size_t) (jl - prev.rest0)] = f;
+          total += f;
+        }
+        // beside-the-bulk rates per free slot (in situ, fp64 MI355X; other types scale alike on both sides)
+        const double cxf = TypeInfo<T>::is_complex ? 4.0 : 1.0;
+        const double below1 = (double) std::max<long>(0, n - (k + 1) * (long) nb), below2 = (double) std::max<long>(0, n - (k + 2) * (long) nb);
+        const double fl_chain = cxf * (double) nb * nb * (below1 + below2) + cxf * 2.0 * (double) nb * nb * below1;  // 2 TRSM + U1
+        const double nblk = (double) nb / kDiagBlock;
+        const double t_chain = 2.0 * nblk * nblk * 11.3e-6 + fl_chain / (5e12 * (double) slots / 32.0);
+        const double t_bulk = total / (66e12 * (1.0 - (double) slots / (double) bulk_slots));
+        const char* force = std::getenv("DLAF_MI355X_U1");  // "main" / "panel": fix the placement
+        u1_on_main = force ? std::strcmp(force, "main") == 0 : t_bulk < t_chain;
+        if (u1_on_main) {
+          double acc = 0;
+          while (splitA < ltc && acc < split_frac * total)
+            acc += colfl[(size_t) (splitA++ - prev.rest0)];
+        }
+      }
+      else if (second && !(prev.valid && prev.rest0 < ltc)) {
+        u1_on_main = true;  // nothing to run beside: plain sequence
+      }
+      if (!u1_on_main)
+        splitA = prev.rest0;  // the whole bulk in one launch, below
+      update(prev, prev.rest0, splitA, s_main, 0, slots);
+      if (second) {
+        if (u1_on_main) {
+          DLAF_HIP_CHECK(hipStreamWaitEvent(s_main, ev_panel[k], 0));
+          update(single(k), k + 1, k + 2, s_main, 1, 0);
+          DLAF_HIP_CHECK(hipEventRecord(ev_head[k], s_main));
+          DLAF_HIP_CHECK(hipStreamWaitEvent(s_panel, ev_head[k], 0));
+        }
+        else {
+          update(single(k), k + 1, k + 2, s_panel, 1, 0);
+        }
         potrf(k + 1);
+        if (more) {
+          trsm(k + 2, ltr, k + 1, tile(k + 1, k + 1), winv_of(k + 1), rows.tile_extent(k + 1), s_panel);
+          DLAF_HIP_CHECK(hipEventRecord(ev_panel[k + 1], s_panel));
+          panels_issued.store(k + 1, std::memory_order_release);
+        }
       }
-      const bool more = k + 2 < nt;         // something trails the pair
-      if (more) {
-        trsm(k + 2, ltr, k + 1, tile(k + 1, k + 1), winv_of(k + 1), rows.tile_extent(k + 1), s_panel);
-        DLAF_HIP_CHECK(hipEventRecord(ev_panel[k + 1], s_panel));
-        panels_issued.store(k + 1, std::memory_order_release);
-      }
-      // the bulk of the previous pair runs beside all of the above
-      update(prev, prev.rest0, ltc, s_main, 0, pair_slots(k, prev));
+      update(prev, splitA, ltc, s_main, 0, slots);
       prev.valid = false;
       if (!more) {
         DLAF_HIP_CHECK(hipEventRecord(ev_diag[k], s_panel));

@@ -124,6 +124,41 @@ void testTriangularSolver(comm::CommunicatorGrid& grid, SizeType m, SizeType n, 
   check_matrix_near<T>(el_x, mat_b, 40 * (m + 1) * TypeUtilities<T>::error, 40 * (m + 1) * TypeUtilities<T>::error, "trsm");
 }
 
+// test/unit/eigensolver/test_gen_to_std.cpp:60-83 (getGenToStdElementSetters, util_generic_lapack.h:96-150, itype 1)
+template <class T>
+void testGenToStd(comm::CommunicatorGrid& grid, blas::Uplo uplo, SizeType m, SizeType mb) {
+  using R = typename TypeUtilities<T>::R;
+  const double alpha = -2.0, beta = 1.5, gamma = .95;
+  matrix::Distribution d(GlobalElementSize(m, m), TileElementSize(mb, mb), grid.size(), grid.rank(), comm::Index2D(0, 0));
+  Matrix<T, Device::CPU> mat_a(d), mat_t(d);
+  auto other = [uplo](const GlobalElementIndex& index) {
+    return (uplo == blas::Uplo::Lower && index.row() < index.col()) || (uplo == blas::Uplo::Upper && index.row() > index.col());
+  };
+  auto el_t = [=](const GlobalElementIndex& index) {
+    if (other(index))
+      return TypeUtilities<T>::element(-9.9, 0);
+    const double i = index.row(), j = index.col();
+    return TypeUtilities<T>::polar(beta / std::exp2(std::abs(i - j)), alpha * (i - j));
+  };
+  auto el_a = [=](const GlobalElementIndex& index) {
+    if (other(index))
+      return TypeUtilities<T>::element(-9.9, 0);
+    const double i = index.row(), j = index.col();
+    return TypeUtilities<T>::polar((i + 1) * (j + 1) * (beta * beta * gamma) / std::exp2(i + j), alpha * (i - j));
+  };
+  auto res_a = [=](const GlobalElementIndex& index) {
+    if (other(index))
+      return TypeUtilities<T>::element(-9.9, 0);
+    const double i = index.row(), j = index.col();
+    return TypeUtilities<T>::polar(gamma / std::exp2(i + j), alpha * (i - j));
+  };
+  matrix::util::set(mat_a, el_a);
+  matrix::util::set(mat_t, el_t);
+  eigensolver::internal::generalized_to_standard<Backend::GPU, T>(grid, uplo, mat_a, mat_t);
+  check_matrix_near<T>(res_a, mat_a, 0, 10 * (m + 1) * TypeUtilities<T>::error, "gen_to_std");
+  check_matrix_near<T>(el_t, mat_t, 0, (R) TypeUtilities<T>::error, "gen_to_std factor untouched");
+}
+
 template <class T>
 void run_type(comm::CommunicatorGrid& grid) {
   for (auto uplo : {blas::Uplo::Lower, blas::Uplo::Upper})
@@ -132,6 +167,9 @@ void run_type(comm::CommunicatorGrid& grid) {
       testCholesky<T>(grid, uplo, m, mb);
     }
   testTriangularSolver<T>(grid, 19, 25, 6);
+  for (auto uplo : {blas::Uplo::Lower, blas::Uplo::Upper})
+    for (const auto& [m, mb] : sizes)
+      testGenToStd<T>(grid, uplo, m, mb);
 }
 
 int main() {

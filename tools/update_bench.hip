@@ -64,7 +64,7 @@ int main(int argc, char** argv) {
   (void) hipEventCreate(&e0);
   (void) hipEventCreate(&e1);
   unsigned* ctr;
-  (void) hipMalloc(&ctr, 8 * sizeof(unsigned));
+  (void) hipMalloc(&ctr, 16 * sizeof(unsigned));
   launch_update(ua, nullptr, 0, max_blocks, ctr);
   (void) hipDeviceSynchronize();
   for (int r = 0; r < reps; ++r) {
