@@ -45,6 +45,7 @@ def parse():
     p.add_argument("--cpu-nb", type=int, default=512)
     p.add_argument("--check", action="store_true", help="check_cholesky of the miniapp on the device after the timed runs (any size, any grid)")
     p.add_argument("--no-check", action="store_true", help="skip the (untimed) device-side residual check at N = 1")
+    p.add_argument("--no-trsm-profile", action="store_true", help="skip the stand-alone panel-TRSM timing (PMC passes: only the factorization's own launches are counted)")
     p.add_argument("--transport", default="rccl", choices=["rccl", "host"],
                    help="host = gloo-staged broadcasts: lets several ranks rehearse the N > 1 path on ONE GPU")
     return p.parse_args()
@@ -201,7 +202,7 @@ def main():
     # the panel TRSM alone on the device (in the factorization it runs beside the bulk update on a few free
     # workgroup slots, so its in-situ duration does not describe the kernel)
     trsm_alone = None
-    if world == 1 and nb * 2 <= n:
+    if world == 1 and nb * 2 <= n and not args.no_trsm_profile:
         trsm_alone = pool[(args.steps - 1) % npool].trsm_profile(5)
 
     if rank == 0:

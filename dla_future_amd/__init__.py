@@ -16,12 +16,12 @@ There is no CPU fallback: importing works anywhere, every compute call needs the
 and a GPU and fails loudly otherwise.
 """
 from .capi import (DLAFDescriptor, LibraryNotBuilt, lib, lib_path, type_char, version)  # noqa: F401
-from .cholesky import (DeviceMatrix, Grid, cholesky_factorization, finalize, generalized_to_standard,  # noqa: F401
+from .cholesky import (DeviceMatrix, GeneralDeviceMatrix, Grid, cholesky_factorization, finalize, generalized_to_standard,  # noqa: F401
                        initialize, make_descriptor, pxhegst, pxpotrf, pxpotrs, pxtrsm, set_random_hermitian_positive_definite, tile_gemm, tile_herk, tile_potrf,
-                       tile_trsm, triangular_solver, solver_profile)
+                       tile_trsm, triangular_solver, triangular_solver_device, potrs_device, solver_profile)
 from . import distribution  # noqa: F401
 
-__all__ = ["DLAFDescriptor", "DeviceMatrix", "Grid", "LibraryNotBuilt", "cholesky_factorization", "distribution",
+__all__ = ["DLAFDescriptor", "DeviceMatrix", "GeneralDeviceMatrix", "Grid", "LibraryNotBuilt", "cholesky_factorization", "distribution",
            "finalize", "generalized_to_standard", "initialize", "lib", "lib_path", "make_descriptor", "pxhegst", "pxpotrf", "pxpotrs", "pxtrsm",
            "set_random_hermitian_positive_definite", "solver_profile", "tile_gemm", "tile_herk", "tile_potrf", "tile_trsm",
-           "triangular_solver", "type_char", "version"]
+           "triangular_solver", "triangular_solver_device", "potrs_device", "type_char", "version"]

@@ -96,6 +96,12 @@ SIGNATURES = {
     "dlaf_mi355x_pcpotrs": (None, [_ch, _i, _i, _vp, _i, _i, _IP, _vp, _i, _i, _IP, _IP]),
     "dlaf_mi355x_pzpotrs": (None, [_ch, _i, _i, _vp, _i, _i, _IP, _vp, _i, _i, _IP, _IP]),
     "dlaf_mi355x_solver_profile": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "dlaf_mi355x_gmatrix_create": (_i, [_i, _ch, DLAFDescriptor, C.POINTER(_vp)]),
+    "dlaf_mi355x_gmatrix_destroy": (None, [_vp]),
+    "dlaf_mi355x_gmatrix_upload": (_i, [_vp, _vp, _i]),
+    "dlaf_mi355x_gmatrix_download": (_i, [_vp, _vp, _i]),
+    "dlaf_mi355x_triangular_solver_device": (_i, [_ch, _ch, _ch, _ch, _vp, _vp, _vp]),
+    "dlaf_mi355x_potrs_device": (_i, [_ch, _vp, _vp]),
     "dlaf_mi355x_generalized_to_standard_s": (_i, [_i, _ch, _vp, DLAFDescriptor, _vp, DLAFDescriptor]),
     "dlaf_mi355x_generalized_to_standard_d": (_i, [_i, _ch, _vp, DLAFDescriptor, _vp, DLAFDescriptor]),
     "dlaf_mi355x_generalized_to_standard_c": (_i, [_i, _ch, _vp, DLAFDescriptor, _vp, DLAFDescriptor]),

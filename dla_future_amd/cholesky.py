@@ -352,6 +352,55 @@ class DeviceMatrix:
             pass
 
 
+class GeneralDeviceMatrix:
+    """A general m x n matrix resident in HBM in tile layout (square blocks): the right-hand sides of a
+    device-resident solve (dlaf_mi355x_gmatrix_*)."""
+
+    def __init__(self, grid: Grid, dtype, m: int, n: int, nb: int, isrc: int = 0, jsrc: int = 0):
+        self.grid, self.dtype, self.m, self.n, self.nb = grid, np.dtype(dtype), m, n, nb
+        self._h = C.c_void_p()
+        desc = DLAFDescriptor(m, n, nb, nb, isrc, jsrc, 0, 0, 1)
+        r = lib().dlaf_mi355x_gmatrix_create(grid.context, type_char(dtype).encode(), desc, C.byref(self._h))
+        if r != 0:
+            raise ValueError(f"dlaf_mi355x_gmatrix_create failed with {r}")
+
+    def upload(self, a: np.ndarray) -> None:
+        assert a.dtype == self.dtype
+        lib().dlaf_mi355x_gmatrix_upload(self._h, _ptr(a), _ld_of(a))
+
+    def download(self, a: np.ndarray) -> None:
+        assert a.dtype == self.dtype
+        lib().dlaf_mi355x_gmatrix_download(self._h, _ptr(a), _ld_of(a))
+
+    def close(self) -> None:
+        if self._h:
+            lib().dlaf_mi355x_gmatrix_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def triangular_solver_device(side: str, uplo: str, op: str, diag: str, alpha, a: DeviceMatrix, b: GeneralDeviceMatrix) -> None:
+    """dlaf::triangular_solver on resident operands: `a` holds the triangular matrix in its uplo triangle (e.g. the
+    factor a.factorize() left there), `b` is overwritten by the solution; no PCIe traffic."""
+    al = np.array([alpha], dtype=b.dtype)
+    r = lib().dlaf_mi355x_triangular_solver_device(side.encode(), uplo.encode(), op.encode(), diag.encode(), _ptr(al),
+                                                   a._h, b._h)
+    if r != 0:
+        raise ValueError(f"dlaf_mi355x_triangular_solver_device failed with {r}")
+
+
+def potrs_device(uplo: str, factor: DeviceMatrix, b: GeneralDeviceMatrix) -> None:
+    """A X = B from the resident Cholesky factor (the two solves of p?potrs, all in HBM)."""
+    r = lib().dlaf_mi355x_potrs_device(uplo.encode(), factor._h, b._h)
+    if r != 0:
+        raise ValueError(f"dlaf_mi355x_potrs_device failed with {r}")
+
+
 # ---- tile operations with the argument sets the factorization issues ----------------------------
 def tile_potrf(uplo: str, a: np.ndarray) -> int:
     """tile::potrf (include/dlaf/lapack/tile.h:362-378); returns info."""

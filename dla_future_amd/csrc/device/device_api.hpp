@@ -167,6 +167,11 @@ template <class T>
 void launch_tile_xform(T* dst, long ldd, long dstride, const T* src, long lds, long sstride, int rows, int cols,
                        int count, int mode, double scale, hipStream_t stream);
 
+// dst tile = alpha * op(src tile) for a batch of tiles; op: 0 adjoint, 3 transpose, 4 conjugate, 5 copy
+template <class T>
+void launch_tile_xform_alpha(T* dst, long ldd, long dstride, const T* src, long lds, long sstride, int rows, int cols,
+                             int count, int mode, T alpha, bool use_alpha, hipStream_t stream);
+
 // checker helpers: max |a_ij| over the lower triangle of the local tiles (into *out, device double) and
 // zeroing of the strict upper part of the local diagonal tiles
 template <class T>

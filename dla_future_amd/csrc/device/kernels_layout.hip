@@ -191,6 +191,63 @@ __global__ __launch_bounds__(kThreads) void tile_xform_kernel(T* dst, long ldd, 
   }
 }
 
+// dst tile = alpha * op(src tile), op: 0 adjoint, 3 transpose, 4 conjugate, 5 copy (0 / 3: rows x cols -> cols x rows).
+// The device-resident triangular solver builds its operand views with it (solver.cpp).
+template <class T>
+__global__ __launch_bounds__(kThreads) void tile_xform_alpha_kernel(T* dst, long ldd, long dstride, const T* src, long lds,
+                                                                    long sstride, int rows, int cols, int mode, T alpha,
+                                                                    int use_alpha) {
+  __shared__ T t[32][33];
+  const int tile = blockIdx.z;
+  const T* s = src + (long) tile * sstride;
+  T* d = dst + (long) tile * dstride;
+  const int tx = threadIdx.x % 32, ty = threadIdx.x / 32;
+  const int bi = blockIdx.x * 32, bj = blockIdx.y * 32;
+  const bool cj = (mode == 0 || mode == 4);
+  auto fin = [&](T v) {
+    if constexpr (TypeInfo<T>::is_complex) {
+      if (cj)
+        v.im = -v.im;
+      if (use_alpha)
+        v = T{v.re * alpha.re - v.im * alpha.im, v.re * alpha.im + v.im * alpha.re};
+    }
+    else {
+      if (use_alpha)
+        v = v * alpha;
+    }
+    return v;
+  };
+  if (mode == 4 || mode == 5) {
+    for (int jj = ty; jj < 32; jj += 8) {
+      const int i = bi + tx, j = bj + jj;
+      if (i < rows && j < cols)
+        d[i + (long) j * ldd] = fin(s[i + (long) j * lds]);
+    }
+    return;
+  }
+  for (int jj = ty; jj < 32; jj += 8) {
+    const int i = bi + tx, j = bj + jj;
+    if (i < rows && j < cols)
+      t[jj][tx] = s[i + (long) j * lds];
+  }
+  __syncthreads();
+  for (int ii = ty; ii < 32; ii += 8) {
+    const int dr = bj + tx, dc = bi + ii;
+    if (dr < cols && dc < rows)
+      d[dr + (long) dc * ldd] = fin(t[tx][ii]);
+  }
+}
+
+template <class T>
+void launch_tile_xform_alpha(T* dst, long ldd, long dstride, const T* src, long lds, long sstride, int rows, int cols,
+                             int count, int mode, T alpha, bool use_alpha, hipStream_t stream) {
+  if (rows <= 0 || cols <= 0 || count <= 0)
+    return;
+  dim3 grid((unsigned) ((rows + 31) / 32), (unsigned) ((cols + 31) / 32), (unsigned) count);
+  hipLaunchKernelGGL((tile_xform_alpha_kernel<T>), grid, dim3(kThreads), 0, stream, dst, ldd, dstride, src, lds, sstride,
+                     rows, cols, mode, alpha, use_alpha ? 1 : 0);
+}
+
 template <class T>
 void launch_tile_xform(T* dst, long ldd, long dstride, const T* src, long lds, long sstride, int rows, int cols,
                        int count, int mode, double scale, hipStream_t stream) {
@@ -299,6 +356,7 @@ void device_kernels_init() {
   template void launch_from_tiles<T>(const LayoutArgs<T>&, hipStream_t);     \
   template void launch_copy2d<T>(T*, long, const T*, long, int, int, int, int, hipStream_t);    \
   template void launch_tile_xform<T>(T*, long, long, const T*, long, long, int, int, int, int, double, hipStream_t); \
+  template void launch_tile_xform_alpha<T>(T*, long, long, const T*, long, long, int, int, int, int, T, bool, hipStream_t); \
   template void launch_max_norm<T>(const T*, int, int, int, long, long, int, int, int, int, double*, hipStream_t); \
   template void launch_zero_upper_diag<T>(T*, int, int, int, int, int, int, int, hipStream_t);
 INST(float)

@@ -226,6 +226,12 @@ __device__ __forceinline__ void glds16(const double* src, double* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) src,
                                    (__attribute__((address_space(3))) void*) lds_dst, 16, 0, 0);
 }
+// non-temporal form (aux = 2) for data a workgroup streams once -- the X strip coming back in P1: it must not push
+// the L tile, which every workgroup of the XCD re-reads, out of the L2
+__device__ __forceinline__ void glds16_nt(const double* src, double* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) src,
+                                   (__attribute__((address_space(3))) void*) lds_dst, 16, 0, 2);
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -270,11 +276,14 @@ __global__ __launch_bounds__(kThreads, (TrsmRowsCfg<NW, ST>::WAVES_PER_SIMD)) vo
     return reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + byte_off);
   };
 
-  auto issue_stage = [&](int c0, int i, int slot) {
+  // with_x: the stage also carries the 8 columns of the X strip (P1 stages; the UPD stages take X from registers)
+  auto issue_stage = [&](int c0, int i, int slot, bool with_x) {
     double* buf = lds + slot * C::STAGE;
     const int col0 = 8 * i;
-    const double* abase = Bst + (long) (col0 + 2 * wave) * ldb;
-    glds16(at(abase, a_lane), buf + 128 * wave);
+    if (with_x) {
+      const double* abase = Bst + (long) (col0 + 2 * wave) * ldb;
+      glds16_nt(at(abase, a_lane), buf + 128 * wave);
+    }
 #pragma unroll
     for (int q = 0; q < C::LB; ++q) {
       const int piece = wave * C::LB + q;
@@ -297,7 +306,7 @@ __global__ __launch_bounds__(kThreads, (TrsmRowsCfg<NW, ST>::WAVES_PER_SIMD)) vo
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const double* base = Bst + (long) (col0 + 32 * (t4 >> 1) + 8 * v + (t4 & 1)) * ldb;
-        Breg[t4][v] = *at(base, bx_lane);
+        Breg[t4][v] = __builtin_nontemporal_load(at(base, bx_lane));
       }
   };
 
@@ -317,17 +326,18 @@ __global__ __launch_bounds__(kThreads, (TrsmRowsCfg<NW, ST>::WAVES_PER_SIMD)) vo
 #pragma unroll
     for (int st = 0; st < ST - 1; ++st)
       if (st < NSTG)
-        issue_stage(c0, st, st);
+        issue_stage(c0, st, st, st < P);
     if (NSTG >= ST - 1)
-      wait_vmcnt<C::LPS*(ST - 2)>();              // stage 0 (and the older W / B loads) landed
+      wait_vmcnt<C::LB*(ST - 2)>();               // stage 0 (and the older W / B loads) landed
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     int slot = 0, nslot = ST - 1;
     auto ring_step_end = [&](int i) {
       // stage i + 1 landed?  loads allowed to stay in flight: stages i+2 .. i+ST-1 when they exist
+      // (count by the SMALLEST stage, LB loads per wave: never lets a stage that must have landed stay in flight)
       if (i + ST - 1 < NSTG)
-        wait_vmcnt<C::LPS*(ST - 2)>();
+        wait_vmcnt<C::LB*(ST - 2)>();
       else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -339,7 +349,7 @@ __global__ __launch_bounds__(kThreads, (TrsmRowsCfg<NW, ST>::WAVES_PER_SIMD)) vo
     // ---- P1: S += X[:, 8i .. 8i+7] L[c0 .. c0+NW, 8i .. 8i+7]^H --------------------------------------
     for (int i = 0; i < P; ++i) {
       if (i + ST - 1 < NSTG)
-        issue_stage(c0, i + ST - 1, nslot);
+        issue_stage(c0, i + ST - 1, nslot, i + ST - 1 < P);
       const double* buf = lds + slot * C::STAGE;
 #pragma unroll
       for (int k4 = 0; k4 < 2; ++k4) {
@@ -420,7 +430,7 @@ __global__ __launch_bounds__(kThreads, (TrsmRowsCfg<NW, ST>::WAVES_PER_SIMD)) vo
       for (int uu = 0; uu < 8; ++uu) {
         const int i = P + 8 * s + uu;
         if (i + ST - 1 < NSTG)
-          issue_stage(c0, i + ST - 1, nslot);
+          issue_stage(c0, i + ST - 1, nslot, false);
         const double* buf = lds + slot * C::STAGE + C::A_ELEMS;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {

@@ -71,13 +71,16 @@ __global__ __launch_bounds__(kThreads, 1) void trsm_rows_z_kernel(TrsmArgs<cdoub
   };
   constexpr int PPC = NW / 64;  // pieces per column of the L image
 
-  auto issue_stage = [&](int c0, int i, int slot) {
+  // with_x: the stage also carries the 8 columns of the X strip (P1 stages; the UPD stages take X from registers)
+  auto issue_stage = [&](int c0, int i, int slot, bool with_x) {
     cdouble* buf = lds + slot * C::STAGE;
     const int col0 = 8 * i;
+    if (with_x) {
 #pragma unroll
-    for (int q = 0; q < C::LA; ++q) {  // X strip: piece = one column of 64 rows
-      const int piece = wave * C::LA + q;
-      glds(at(Bst + (long) (col0 + piece) * ldb, pc_lane), buf + 64 * piece);
+      for (int q = 0; q < C::LA; ++q) {  // X strip: piece = one column of 64 rows
+        const int piece = wave * C::LA + q;
+        glds(at(Bst + (long) (col0 + piece) * ldb, pc_lane), buf + 64 * piece);
+      }
     }
 #pragma unroll
     for (int q = 0; q < C::LB; ++q) {
@@ -107,7 +110,8 @@ __global__ __launch_bounds__(kThreads, 1) void trsm_rows_z_kernel(TrsmArgs<cdoub
       }
   };
   auto wait_ring = [&]() {
-    __builtin_amdgcn_s_waitcnt(0x0F70 | ((C::LPS * (ST - 2)) & 0xF) | ((((C::LPS * (ST - 2)) >> 4) & 0x3) << 14));
+    // counted by the smallest stage (LB loads per wave): a stage that must have landed never stays in flight
+    __builtin_amdgcn_s_waitcnt(0x0F70 | ((C::LB * (ST - 2)) & 0xF) | ((((C::LB * (ST - 2)) >> 4) & 0x3) << 14));
   };
 
   const int nmacro = p.n / NW;
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(kThreads, 1) void trsm_rows_z_kernel(TrsmArgs<cdoub
 #pragma unroll
     for (int st = 0; st < ST - 1; ++st)
       if (st < NSTG)
-        issue_stage(c0, st, st);
+        issue_stage(c0, st, st, st < P);
     if (NSTG >= ST - 1)
       wait_ring();
     else
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(kThreads, 1) void trsm_rows_z_kernel(TrsmArgs<cdoub
     // ---- P1: S += X[:, 8i .. 8i+7] L[c0 .. c0+NW, 8i .. 8i+7]^H ------------------------------------
     for (int i = 0; i < P; ++i) {
       if (i + ST - 1 < NSTG)
-        issue_stage(c0, i + ST - 1, nslot);
+        issue_stage(c0, i + ST - 1, nslot, i + ST - 1 < P);
       const cdouble* buf = lds + slot * C::STAGE;
 #pragma unroll
       for (int k4 = 0; k4 < 2; ++k4) {
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(kThreads, 1) void trsm_rows_z_kernel(TrsmArgs<cdoub
       for (int uu = 0; uu < 8; ++uu) {
         const int i = P + 8 * s + uu;
         if (i + ST - 1 < NSTG)
-          issue_stage(c0, i + ST - 1, nslot);
+          issue_stage(c0, i + ST - 1, nslot, false);
         const cdouble* buf = lds + slot * C::STAGE + C::A_ELEMS;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {

@@ -481,6 +481,70 @@ DLAF_MI355X_HEGST_ENTRY(c, std::complex<float>, dlaf_complex_c, float)
 DLAF_MI355X_HEGST_ENTRY(z, std::complex<double>, dlaf_complex_z, double)
 #undef DLAF_MI355X_HEGST_ENTRY
 
+// ---- device-resident operands for the solver ----------------------------------------------------------------
+struct dlaf_mi355x_gmatrix_s {
+  std::unique_ptr<MatrixBase> m;
+  int ctx;
+};
+
+int dlaf_mi355x_gmatrix_create(int ctx, char type, DLAF_descriptor d, dlaf_mi355x_gmatrix_t* out) noexcept {
+  if (!out)
+    return -1;
+  auto it = g_grids.find(ctx);
+  if (it == g_grids.end())
+    return -1;
+  Grid* g = it->second.get();
+  if (d.i != 0 || d.j != 0 || d.m < 0 || d.n < 0 || d.mb != d.nb || d.nb < 1)
+    return -3;  // square blocks only in this build
+  if (d.isrc < 0 || d.isrc >= g->nprow || d.jsrc < 0 || d.jsrc >= g->npcol)
+    return -3;
+  MatrixBase* m = general_matrix_create(g, type, d.m, d.n, d.nb, d.isrc, d.jsrc);
+  if (!m)
+    return -2;
+  auto* h = new dlaf_mi355x_gmatrix_s;
+  h->m.reset(m);
+  h->ctx = ctx;
+  *out = h;
+  return 0;
+}
+void dlaf_mi355x_gmatrix_destroy(dlaf_mi355x_gmatrix_t h) noexcept {
+  delete h;
+}
+int dlaf_mi355x_gmatrix_upload(dlaf_mi355x_gmatrix_t h, const void* host, int ld) noexcept {
+  if (!h || !h->m)
+    return -1;
+  general_matrix_transfer(h->m.get(), const_cast<void*>(host), ld, true);
+  return 0;
+}
+int dlaf_mi355x_gmatrix_download(dlaf_mi355x_gmatrix_t h, void* host, int ld) noexcept {
+  if (!h || !h->m)
+    return -1;
+  general_matrix_transfer(h->m.get(), host, ld, false);
+  return 0;
+}
+int dlaf_mi355x_triangular_solver_device(char side, char uplo, char op, char diag, const void* alpha,
+                                         dlaf_mi355x_matrix_t a, dlaf_mi355x_gmatrix_t b) noexcept {
+  if (!a || !a->m || !b || !b->m || a->ctx != b->ctx)
+    return -1;
+  auto is = [](char c, const char* set) { return c != 0 && std::strchr(set, c) != nullptr; };
+  if (!is(side, "LlRr") || !is(uplo, "LlUu") || !is(op, "NnTtCc") || !is(diag, "NnUu"))
+    fatal("[dlaf_mi355x] triangular solver: bad side/uplo/op/diag '%c' '%c' '%c' '%c'\n", side, uplo, op, diag);
+  return triangular_solver_device(side, uplo, op, diag, alpha, a->m.get(), b->m.get());
+}
+// A X = B from the resident factor (p?potrs without leaving HBM): two solves, nothing crosses PCIe in between
+int dlaf_mi355x_potrs_device(char uplo, dlaf_mi355x_matrix_t factor, dlaf_mi355x_gmatrix_t b) noexcept {
+  if (!factor || !factor->m || !b || !b->m)
+    return -1;
+  const bool lower = (uplo == 'L' || uplo == 'l');
+  const double one_d[2] = {1.0, 0.0};
+  const float one_f[2] = {1.0f, 0.0f};
+  const void* one = (factor->type == 's' || factor->type == 'c') ? (const void*) one_f : (const void*) one_d;
+  int r = dlaf_mi355x_triangular_solver_device('L', uplo, lower ? 'N' : 'C', 'N', one, factor, b);
+  if (r != 0)
+    return r;
+  return dlaf_mi355x_triangular_solver_device('L', uplo, lower ? 'C' : 'N', 'N', one, factor, b);
+}
+
 int dlaf_mi355x_solver_profile(double* ms, double* flops) noexcept {
   solver_last_profile(ms, flops);
   return 0;

@@ -644,11 +644,12 @@ void DeviceMatrix<T>::factorize_async() {
   // one process: the bulk update takes the panels of TWO steps per pass (K = 2 nb): half the read-modify-write
   // traffic of the trailing matrix, half the launches, half the per-block epilogues -- what a small block
   // size loses against nb = 1024, and 1.5 % at nb = 1024 itself (DLAF_MI355X_SCHEDULE=pairs; default for one
-  // process, real types; measured fp64: N=32768 nb=512 55.0 -> 57.2 TFlop/s, N=65536 nb=1024 64.9 -> 65.9)
+  // process; measured fp64: N=32768 nb=512 55.0 -> 57.2 TFlop/s, N=65536 nb=1024 64.9 -> 65.9; z N=32768 nb=512
+  // 57.3 -> 59.7)
   const bool pairs = [&] {
     if (const char* e = std::getenv("DLAF_MI355X_SCHEDULE"))
       return std::strcmp(e, "pairs") == 0 && !dist;
-    return !dist && !TypeInfo<T>::is_complex && nb % 16 == 0;
+    return !dist && nb % 16 == 0;
   }();
   const long sidecar_slots = [&]() -> long {
     if (const char* e = std::getenv("DLAF_MI355X_SIDECAR_SLOTS"))

@@ -219,6 +219,13 @@ int triangular_solver_host(Grid* g, char side, char uplo, char op, char diag, T 
 
 void solver_last_profile(double* ms, double* flops);
 
+// Device-resident operands for the solver (solver.cpp): a general m x n matrix in tile layout behind a MatrixBase
+// handle, and dlaf::triangular_solver on a resident triangular matrix (a DeviceMatrix, e.g. the factor p?potrf left
+// there) and a resident right-hand side -- no PCIe traffic.
+MatrixBase* general_matrix_create(Grid* g, char type, long m, long n, int nb, int isrc, int jsrc);
+void general_matrix_transfer(MatrixBase* h, void* host, long ld, bool upload);
+int triangular_solver_device(char side, char uplo, char op, char diag, const void* alpha, MatrixBase* a, MatrixBase* b);
+
 // A <- L^-1 A L^-H (uplo L) / U^-H A U^-1 (uplo U) with the Cholesky factor held in the same uplo triangle of
 // `l` (gen_to_std.cpp; dlaf::eigensolver::internal::generalized_to_standard); device-resident and host forms
 template <class T>

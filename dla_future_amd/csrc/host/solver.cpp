@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "runtime.hpp"
@@ -59,9 +60,10 @@ struct TileMatrix {
   size_t tile_elems = 0;
   T* tiles = nullptr;
   T* staging = nullptr;
+  bool owns = true;  // false: `tiles` belongs to somebody else (a view over a resident matrix)
 
   // m_src x n_src: global size of the caller's matrix, (isrc, jsrc) its source process
-  void create(Grid* g, bool transposed_, long m_src, long n_src, int nb_, int isrc, int jsrc) {
+  void create(Grid* g, bool transposed_, long m_src, long n_src, int nb_, int isrc, int jsrc, T* borrow = nullptr) {
     grid = g;
     transposed = transposed_;
     nb = nb_;
@@ -72,10 +74,11 @@ struct TileMatrix {
     ltr = rows.local_tiles();
     ltc = cols.local_tiles();
     tile_elems = (size_t) nb * nb;
-    tiles = dev_alloc<T>((size_t) ltr * ltc * tile_elems);
+    owns = borrow == nullptr;
+    tiles = owns ? dev_alloc<T>((size_t) ltr * ltc * tile_elems) : borrow;
   }
   ~TileMatrix() {
-    if (tiles)
+    if (tiles && owns)
       (void) hipFree(tiles);
     if (staging)
       (void) hipFree(staging);
@@ -143,6 +146,20 @@ T conj_el(T v) {
     v.im = -v.im;
   return v;
 }
+template <class T>
+double re_of_host(const T& v) {
+  if constexpr (TypeInfo<T>::is_complex)
+    return (double) v.re;
+  else
+    return (double) v;
+}
+template <class T>
+double im_of_host(const T& v) {
+  if constexpr (TypeInfo<T>::is_complex)
+    return (double) v.im;
+  else
+    return 0.0;
+}
 
 // device time of the last sweep on this process (HIP events on the compute stream; relayout and PCIe excluded)
 static double g_last_sweep_ms = 0;
@@ -167,7 +184,7 @@ struct Events {
 template <class T>
 void solve_canonical(TileMatrix<T>& Td, TileMatrix<T>& Bd, bool upper, bool unit) {
   Grid* g = Bd.grid;
-  Transport* tr = g->transport.get();
+  Transport* tr = grid_transport(*g);
   const bool dist = g->nranks > 1;
   const int nb = Bd.nb;
   const long nt = Bd.cols.nt();  // tiles along n
@@ -547,6 +564,166 @@ int triangular_solver_host(Grid* g, char side, char uplo, char op, char diag, T 
   }
   DLAF_HIP_CHECK(hipStreamDestroy(s));
   return 0;
+}
+
+// ================================================================================ device-resident operands
+// A general m x n matrix resident in HBM in tile layout (the right-hand sides of a solve), behind an opaque handle.
+template <class T>
+struct GeneralMatrix : MatrixBase {
+  TileMatrix<T> m;
+  long rows_g = 0, cols_g = 0;
+  int isrc = 0, jsrc = 0;
+};
+
+MatrixBase* general_matrix_create(Grid* g, char type, long m, long n, int nb, int isrc, int jsrc) {
+  runtime_init();
+  (void) grid_transport(*g);
+  auto make = [&](auto* tag) -> MatrixBase* {
+    using T = std::remove_pointer_t<decltype(tag)>;
+    auto* gm = new GeneralMatrix<T>;
+    gm->type = type;
+    gm->rows_g = m;
+    gm->cols_g = n;
+    gm->isrc = isrc;
+    gm->jsrc = jsrc;
+    gm->m.create(g, false, m, n, nb, isrc, jsrc);
+    return gm;
+  };
+  switch (type) {
+    case 's': return make((float*) nullptr);
+    case 'd': return make((double*) nullptr);
+    case 'c': return make((cfloat*) nullptr);
+    case 'z': return make((cdouble*) nullptr);
+    default: return nullptr;
+  }
+}
+
+template <class T>
+static void gm_transfer(GeneralMatrix<T>& gm, void* host, long ld, bool up) {
+  hipStream_t s = nullptr;
+  DLAF_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  if (up)
+    gm.m.upload(static_cast<const T*>(host), ld, false, false, T{}, s);
+  else
+    gm.m.download(static_cast<T*>(host), ld, false, s);
+  DLAF_HIP_CHECK(hipStreamSynchronize(s));
+  DLAF_HIP_CHECK(hipStreamDestroy(s));
+}
+
+void general_matrix_transfer(MatrixBase* h, void* host, long ld, bool upload) {
+  switch (h->type) {
+    case 's': gm_transfer(static_cast<GeneralMatrix<float>&>(*h), host, ld, upload); break;
+    case 'd': gm_transfer(static_cast<GeneralMatrix<double>&>(*h), host, ld, upload); break;
+    case 'c': gm_transfer(static_cast<GeneralMatrix<cfloat>&>(*h), host, ld, upload); break;
+    case 'z': gm_transfer(static_cast<GeneralMatrix<cdouble>&>(*h), host, ld, upload); break;
+    default: fatal("[dlaf_mi355x] bad matrix type\n");
+  }
+}
+
+// dst view tile (il, jl) = alpha * op(src tile): src (il, jl) for the copying ops (4 conjugate, 5 copy), src (jl, il)
+// for the transposing ones (0 adjoint, 3 transpose).  A transposed view of a block-cyclic matrix stays on the
+// same process (tile (i,j) of the view is tile (j,i) of the source), so this is local work on every rank.
+template <class T>
+static void xform_tiles(T* dst, long dltr, long dltc, const T* src, long sltr, size_t te, int nb, int mode, T alpha,
+                        bool use_alpha, hipStream_t s) {
+  const bool tr = (mode == 0 || mode == 3);
+  for (long jl = 0; jl < dltc; ++jl) {
+    // view column jl, all view rows: src tiles (il, jl) [stride te] or (jl, il) [stride sltr * te]
+    const T* sp = tr ? src + (size_t) jl * te : src + (size_t) jl * sltr * te;
+    launch_tile_xform_alpha(dst + (size_t) jl * dltr * te, (long) nb, (long) te, sp, (long) nb,
+                            tr ? (long) (sltr * te) : (long) te, nb, nb, (int) dltr, mode, alpha, use_alpha, s);
+  }
+}
+
+// dlaf::triangular_solver on RESIDENT operands: A = a DeviceMatrix (its uplo triangle: a Cholesky factor, or any
+// triangular matrix uploaded as such), B = a general resident matrix, overwritten by the solution.  Nothing crosses
+// PCIe: the operand views of the one device algorithm (X T^H = B) are made by tile transforms on the device.
+template <class T>
+static int solver_device(char side, char uplo, char op, char diag, T alpha, DeviceMatrix<T>& A, GeneralMatrix<T>& B) {
+  Grid* g = A.grid;
+  if (B.m.grid != g)
+    fatal("[dlaf_mi355x] triangular solver: A and B live on different grids\n");
+  const bool left = (side == 'L' || side == 'l');
+  const bool a_upper = (uplo == 'U' || uplo == 'u');
+  if (a_upper != A.transposed)
+    fatal("[dlaf_mi355x] triangular solver: uplo '%c' but the resident matrix holds its '%c' triangle\n", uplo, A.uplo);
+  const char o = (op == 'n') ? 'N' : (op == 't') ? 'T' : (op == 'c') ? 'C' : op;
+  const bool unit = (diag == 'U' || diag == 'u');
+  const long m = B.rows_g, n = B.cols_g, na = left ? m : n;
+  const int nb = A.nb;
+  if (A.n != na || B.m.nb != nb)
+    fatal("[dlaf_mi355x] triangular solver: A is %ld x %ld (block %d), B is %ld x %ld (block %d), side %c\n", A.n, A.n,
+          nb, m, n, B.m.nb, side);
+  if (m == 0 || n == 0)
+    return 0;
+  // the caller's A and its source process (the DeviceMatrix holds the transposed view for uplo U)
+  const Axis& a_rows = A.transposed ? A.cols : A.rows;
+  const Axis& a_cols = A.transposed ? A.rows : A.cols;
+  if (left ? (a_rows.src != B.isrc) : (a_cols.src != B.jsrc))
+    fatal("[dlaf_mi355x] triangular solver: A and B must share the source process along the triangular dimension\n");
+  // T = A (Right C / Left N), A^H (Right N / Left C), conj(A) (Right T), A^T (Left T) -- as in triangular_solver_host
+  bool t_transposed, t_conj;
+  if (left) {
+    t_transposed = (o != 'N');
+    t_conj = (o == 'C');
+  }
+  else {
+    t_transposed = (o == 'N');
+    t_conj = (o == 'N' || o == 'T');
+  }
+  const bool t_upper = a_upper != t_transposed;
+  // in terms of the STORED tiles S (S = A for uplo L, S = A^T for uplo U): T = op(S)
+  const bool s_transpose = t_transposed != A.transposed;
+  const int t_mode = s_transpose ? (t_conj ? 0 : 3) : (t_conj ? 4 : 5);
+
+  hipStream_t s = nullptr;
+  DLAF_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  {
+    TileMatrix<T> Td, Bd;
+    const size_t te = A.tile_elems;
+    if (t_mode == 5) {
+      Td.create(g, t_transposed, na, na, nb, a_rows.src, a_cols.src, A.tiles);  // T is the stored matrix itself
+    }
+    else {
+      Td.create(g, t_transposed, na, na, nb, a_rows.src, a_cols.src);
+      xform_tiles(Td.tiles, Td.ltr, Td.ltc, A.tiles, A.ltr, te, nb, t_mode, T{}, false, s);
+    }
+    const bool scale = !(re_of_host(alpha) == 1 && im_of_host(alpha) == 0);
+    if (left) {
+      // B_dev = (alpha B)^H = conj(alpha) B^H
+      Bd.create(g, true, m, n, nb, B.isrc, B.jsrc);
+      xform_tiles(Bd.tiles, Bd.ltr, Bd.ltc, B.m.tiles, B.m.ltr, te, nb, 0, conj_el(alpha), scale, s);
+    }
+    else {
+      Bd.create(g, false, m, n, nb, B.isrc, B.jsrc, B.m.tiles);  // in place
+      if (scale)
+        xform_tiles(Bd.tiles, Bd.ltr, Bd.ltc, B.m.tiles, B.m.ltr, te, nb, 5, alpha, true, s);
+    }
+    DLAF_HIP_CHECK(hipStreamSynchronize(s));
+    solve_canonical(Td, Bd, t_upper, unit);
+    if (left) {
+      xform_tiles(B.m.tiles, B.m.ltr, B.m.ltc, Bd.tiles, Bd.ltr, te, nb, 0, T{}, false, s);
+      DLAF_HIP_CHECK(hipStreamSynchronize(s));
+    }
+  }
+  DLAF_HIP_CHECK(hipStreamDestroy(s));
+  return 0;
+}
+
+int triangular_solver_device(char side, char uplo, char op, char diag, const void* alpha, MatrixBase* a, MatrixBase* b) {
+  if (!a || !b || a->type != b->type)
+    fatal("[dlaf_mi355x] triangular solver: operands of different element types\n");
+  switch (a->type) {
+    case 's': return solver_device<float>(side, uplo, op, diag, *static_cast<const float*>(alpha),
+                                          static_cast<DeviceMatrix<float>&>(*a), static_cast<GeneralMatrix<float>&>(*b));
+    case 'd': return solver_device<double>(side, uplo, op, diag, *static_cast<const double*>(alpha),
+                                           static_cast<DeviceMatrix<double>&>(*a), static_cast<GeneralMatrix<double>&>(*b));
+    case 'c': return solver_device<cfloat>(side, uplo, op, diag, *static_cast<const cfloat*>(alpha),
+                                           static_cast<DeviceMatrix<cfloat>&>(*a), static_cast<GeneralMatrix<cfloat>&>(*b));
+    case 'z': return solver_device<cdouble>(side, uplo, op, diag, *static_cast<const cdouble*>(alpha),
+                                            static_cast<DeviceMatrix<cdouble>&>(*a), static_cast<GeneralMatrix<cdouble>&>(*b));
+    default: fatal("[dlaf_mi355x] bad matrix type\n");
+  }
 }
 
 template int triangular_solver_host<float>(Grid*, char, char, char, char, float, const float*, long, int, int, float*,

@@ -193,6 +193,20 @@ DLAF_EXTERN_C void dlaf_mi355x_pzhegst(int ibtype, char uplo, int n, dlaf_comple
 DLAF_EXTERN_C int dlaf_mi355x_generalized_to_standard_device(dlaf_mi355x_matrix_t a,
                                                              dlaf_mi355x_matrix_t cholesky_factor_of_b) DLAF_NOEXCEPT;
 
+/* Device-resident operands: a general m x n matrix in HBM (tile layout; square blocks) as the right-hand side,
+ * a dlaf_mi355x_matrix_t (the uplo triangle of a resident matrix, e.g. the factor dlaf_mi355x_cholesky_* left there)
+ * as the triangular matrix.  b is overwritten by the solution; nothing crosses PCIe.  potrs_device = the two solves of
+ * A X = B from the resident Cholesky factor.  Same requirements as the host entry. */
+typedef struct dlaf_mi355x_gmatrix_s* dlaf_mi355x_gmatrix_t;
+DLAF_EXTERN_C int dlaf_mi355x_gmatrix_create(int context, char type, struct DLAF_descriptor desc,
+                                             dlaf_mi355x_gmatrix_t* out) DLAF_NOEXCEPT;
+DLAF_EXTERN_C void dlaf_mi355x_gmatrix_destroy(dlaf_mi355x_gmatrix_t m) DLAF_NOEXCEPT;
+DLAF_EXTERN_C int dlaf_mi355x_gmatrix_upload(dlaf_mi355x_gmatrix_t m, const void* host_local, int ld) DLAF_NOEXCEPT;
+DLAF_EXTERN_C int dlaf_mi355x_gmatrix_download(dlaf_mi355x_gmatrix_t m, void* host_local, int ld) DLAF_NOEXCEPT;
+DLAF_EXTERN_C int dlaf_mi355x_triangular_solver_device(char side, char uplo, char op, char diag, const void* alpha,
+                                                       dlaf_mi355x_matrix_t a, dlaf_mi355x_gmatrix_t b) DLAF_NOEXCEPT;
+DLAF_EXTERN_C int dlaf_mi355x_potrs_device(char uplo, dlaf_mi355x_matrix_t factor, dlaf_mi355x_gmatrix_t b) DLAF_NOEXCEPT;
+
 /* Device time (ms, HIP events on the compute stream) of the sweep of the last triangular solve on this process
  * -- relayout and PCIe staging excluded -- and the whole-grid algorithmic flops it stands for (m n^2 for side
  * R, m^2 n for side L; x4 complex). */

@@ -271,6 +271,33 @@ def main():
                 if not good:
                     print(f"[dist_worker] gen_to_std random FAILED {t}{uplo} n={n} nb={nb}: max diff {md} tol {tol}", flush=True)
                 ok &= bool(good)
+        # p?potrf -> p?potrs on resident matrices over the grid (no host staging between the factorization and the
+        # two solves), and one resident solve per side against the oracle
+        for t, uplo, n, nrhs, nb in [("d", "L", 300, 90, 32), ("z", "U", 200, 70, 32)]:
+            dt = oracle.DTYPES[t]
+            a0 = oracle.set_random_hpd(n, nb, dt)
+            rng = np.random.default_rng(5)
+            xs = rng.uniform(-1, 1, (n, nrhs)) + (1j * rng.uniform(-1, 1, (n, nrhs)) if t == "z" else 0)
+            xs = np.asfortranarray(xs.astype(dt))
+            rhs = np.asfortranarray(a0 @ xs)
+            sr, sc = max(0, nprow - 1), min(1, npcol - 1)
+            la = np.asfortranarray(oracle.scatter(a0, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
+            lb = np.asfortranarray(oracle.scatter(rhs, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
+            am = dlaf.DeviceMatrix(grid, dt, uplo, n, nb, sr, sc)
+            am.upload(la)
+            bm = dlaf.GeneralDeviceMatrix(grid, dt, n, nrhs, nb, sr, sc)
+            bm.upload(lb)
+            ok &= am.factorize() == 0
+            dlaf.potrs_device(uplo, am, bm)
+            bm.download(lb)
+            got = gather_global(lb, grid, nrhs, nb, sr, sc, oracle, m=n)
+            if rank == 0:
+                good = bool(np.abs(got - xs).max() <= 100 * n * oracle.eps_of(dt))
+                if not good:
+                    print(f"[dist_worker] resident potrs FAILED {t}{uplo}: max diff {np.abs(got - xs).max()}", flush=True)
+                ok &= good
+            am.close()
+            bm.close()
         # analytic known-answer matrix through the ScaLAPACK-style entry (test_cholesky_c_api.cpp:108-155)
         n, nb = 34, 13
         a, l = oracle.cholesky_setters("L", n, np.float64)

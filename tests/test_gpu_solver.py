@@ -98,3 +98,59 @@ def test_pdtrsm_after_pdpotrf_solves_the_system(dlaf, grid, oracle):
     assert dlaf.pxpotrf("U", n, fact, 1, 1, desca) == 0
     assert dlaf.pxpotrs("U", n, nrhs, fact, 1, 1, desca, rhs, 1, 1, descb) == 0
     assert np.abs(rhs - xs).max() <= 100 * n * oracle.eps_of(np.float64)
+
+
+@pytest.mark.parametrize("t", TYPES)
+def test_triangular_solver_on_resident_operands(dlaf, grid, oracle, t):
+    """dlaf_mi355x_triangular_solver_device: the triangular matrix in the uplo triangle of a resident matrix, the
+    right-hand sides in a resident general matrix, every side / uplo / op / diag against the oracle's trsm; the
+    other triangle of A holds junk that must not be read."""
+    dt = oracle.DTYPES[t]
+    rng = np.random.default_rng(11)
+    cx = t in "cz"
+    for (m, n, nb), side, uplo, op, diag in itertools.product([(260, 200, 64), (129, 257, 128)], "LR", "LU", "NTC", "NU"):
+        na = m if side == "L" else n
+        a = rng.uniform(-1, 1, (na, na)) + (1j * rng.uniform(-1, 1, (na, na)) if cx else 0)
+        a = (a / na + 2 * np.eye(na)).astype(dt)
+        tri = np.tril(a) if uplo == "L" else np.triu(a)
+        junk = np.full((na, na), dt(-9.9))
+        a_in = np.asfortranarray(tri + (np.triu(junk, 1) if uplo == "L" else np.tril(junk, -1)))
+        b = np.asfortranarray((rng.uniform(-1, 1, (m, n)) + (1j * rng.uniform(-1, 1, (m, n)) if cx else 0)).astype(dt))
+        alpha = dt(complex(.7, -.4)) if cx else dt(.7)
+        ref = b.copy(order="F")
+        oracle.trsm(side, uplo, op, diag, alpha, np.asfortranarray(tri), ref)
+        am = dlaf.DeviceMatrix(grid, dt, uplo, na, nb)
+        am.upload(a_in)
+        bm = dlaf.GeneralDeviceMatrix(grid, dt, m, n, nb)
+        bm.upload(b)
+        dlaf.triangular_solver_device(side, uplo, op, diag, alpha, am, bm)
+        got = np.zeros((m, n), dtype=dt, order="F")
+        bm.download(got)
+        tol = 40 * (m + 1) * err_of(oracle, t)
+        ok, md = oracle.check_near(ref, got, tol, tol)
+        assert ok, (md, tol, m, n, nb, side, uplo, op, diag)
+        am.close()
+        bm.close()
+
+
+@pytest.mark.parametrize("t,uplo", [("d", "L"), ("d", "U"), ("z", "L"), ("z", "U")])
+def test_potrf_then_potrs_without_leaving_hbm(dlaf, grid, oracle, t, uplo):
+    """p?potrf -> p?potrs chained on resident matrices: upload A and B once, factor, solve, download X."""
+    dt = oracle.DTYPES[t]
+    n, nrhs, nb = 600, 200, 128
+    a0 = oracle.set_random_hpd(n, nb, dt)
+    rng = np.random.default_rng(5)
+    xs = rng.uniform(-1, 1, (n, nrhs)) + (1j * rng.uniform(-1, 1, (n, nrhs)) if t == "z" else 0)
+    xs = np.asfortranarray(xs.astype(dt))
+    rhs = np.asfortranarray(a0 @ xs)
+    am = dlaf.DeviceMatrix(grid, dt, uplo, n, nb)
+    am.upload(a0)
+    bm = dlaf.GeneralDeviceMatrix(grid, dt, n, nrhs, nb)
+    bm.upload(rhs)
+    assert am.factorize() == 0
+    dlaf.potrs_device(uplo, am, bm)
+    got = np.zeros((n, nrhs), dtype=dt, order="F")
+    bm.download(got)
+    assert np.abs(got - xs).max() <= 100 * n * oracle.eps_of(dt)
+    am.close()
+    bm.close()

@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 : > $OUT/pmc_hbm_traffic.txt
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$ctr
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$ctr -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-check "$@" > $OUT/bench_under_pmc_$ctr.log 2>&1
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$ctr -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-check --no-trsm-profile "$@" > $OUT/bench_under_pmc_$ctr.log 2>&1
   python3 $ROOT/tools/pmc_summary.py /tmp/pmc_$ctr _kernel >> $OUT/pmc_hbm_traffic.txt
 done
 cat $OUT/pmc_hbm_traffic.txt
