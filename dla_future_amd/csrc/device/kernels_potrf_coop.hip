@@ -42,6 +42,15 @@ struct CoopCfg {
 
 constexpr unsigned kCoopFailed = 0x40000000u;
 constexpr long kCoopSpinLimit = 40000000;  // x (s_sleep + L2 round trip) >> any legitimate wait
+// the bound every wait of a launch uses: kCoopSpinLimit, or DLAF_MI355X_POTRF_SPIN_LIMIT (tests use a tiny value
+// to drive the expiry path: flag -> kInfoSchedulingFailure -> the host refuses the result)
+static long coop_spin_limit() {
+  static const long v = [] {
+    const char* e = std::getenv("DLAF_MI355X_POTRF_SPIN_LIMIT");
+    return e ? std::atol(e) : kCoopSpinLimit;
+  }();
+  return v;
+}
 
 // Write-through (sc1) store of one element: the bytes another workgroup will read are stored this way,
 // so publishing needs NO agent-scope release fence.  That fence (buffer_wbl2) writes back every dirty
@@ -84,13 +93,13 @@ __device__ __forceinline__ void coop_publish(unsigned* word, unsigned value, boo
 }
 
 // all threads call; returns the observed value (>= target), or 0xFFFFFFFF after the spin bound
-__device__ __forceinline__ unsigned coop_wait(unsigned* word, unsigned target, unsigned* shared_slot) {
+__device__ __forceinline__ unsigned coop_wait(unsigned* word, unsigned target, unsigned* shared_slot, long spin_limit) {
   if (threadIdx.x == 0) {
     unsigned v;
     long spins = 0;
     while ((v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
       __builtin_amdgcn_s_sleep(16);
-      if (++spins > kCoopSpinLimit) {
+      if (++spins > spin_limit) {
         v = 0xFFFFFFFFu;
         break;
       }
@@ -107,7 +116,7 @@ __device__ __forceinline__ unsigned coop_wait(unsigned* word, unsigned target, u
 
 // all threads call: waits until every word of words[0 .. n) is non-zero (thread i polls word i); returns false
 // after the spin bound.  n <= kThreads.
-__device__ __forceinline__ bool coop_wait_all(unsigned* words, int n, unsigned* shared_slot) {
+__device__ __forceinline__ bool coop_wait_all(unsigned* words, int n, unsigned* shared_slot, long spin_limit) {
   if (threadIdx.x == 0)
     *shared_slot = 1u;
   __syncthreads();
@@ -115,7 +124,7 @@ __device__ __forceinline__ bool coop_wait_all(unsigned* words, int n, unsigned* 
     long spins = 0;
     while (__hip_atomic_load(&words[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
       __builtin_amdgcn_s_sleep(16);
-      if (++spins > kCoopSpinLimit) {
+      if (++spins > spin_limit) {
         *shared_slot = 0u;
         break;
       }
@@ -204,7 +213,7 @@ __device__ __forceinline__ void coop_mma64(const real_t<T>* A, const real_t<T>* 
 template <class T>
 __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__ tile, int ld, int kb,
                                                                   T* __restrict__ winv, int* info, int info_base,
-                                                                  unsigned* sync) {
+                                                                  unsigned* sync, long spin_limit) {
   using C = CoopCfg<T>;
   using R = real_t<T>;
   using acc_t = typename Mma<R>::acc_t;
@@ -231,7 +240,7 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
 
   for (int j = 0; j < s; ++j) {
     const int jb = kCB;  // every block column left of my diagonal block is full
-    const unsigned f = coop_wait(&flag[j], 1u, &wait_slot);
+    const unsigned f = coop_wait(&flag[j], 1u, &wait_slot, spin_limit);
     if (f != 1u) {
       // not positive definite (info already set by the owner), or the spin bound was hit
       if (f == 0xFFFFFFFFu && t == 0)
@@ -260,7 +269,7 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
       }
     coop_publish(&xflag[(long) j * G + s], 1u, false);
     // the updates below read X(c, j) of the strips j < c < s (my own X_s is in LDS)
-    if (s - j - 1 > 0 && !coop_wait_all(&xflag[(long) j * G + j + 1], s - j - 1, &wait_slot)) {
+    if (s - j - 1 > 0 && !coop_wait_all(&xflag[(long) j * G + j + 1], s - j - 1, &wait_slot, spin_limit)) {
       if (t == 0)
         atomicCAS(info, 0, kInfoSchedulingFailure);
       return;
@@ -397,7 +406,7 @@ void launch_potrf_coop(T* tile, int ld, int kb, T* winv, int* info, int info_bas
     fatal_device_config("potrf_coop: more than 256 strips per tile");
   (void) hipMemsetAsync(sync, 0, sizeof(unsigned) * ((size_t) G + (size_t) G * G), stream);
   hipLaunchKernelGGL((potrf_coop_kernel<T>), dim3((unsigned) G), dim3(kThreads), CoopCfg<T>::LDS_BYTES, stream, tile, ld,
-                     kb, winv, info, info_base, sync);
+                     kb, winv, info, info_base, sync, coop_spin_limit());
 }
 
 template <class T>

@@ -406,6 +406,19 @@ void generalized_to_standard(comm::CommunicatorGrid& grid, blas::Uplo uplo, Matr
   if (r != 0)
     dlaf::internal::fail("generalized_to_standard");
 }
+// device-resident operands (the reference's miniapp times exactly this: both mirrors on the device,
+// miniapp_gen_to_std.cpp:119-140); mat_b holds the Cholesky factor, e.g. straight from cholesky_factorization
+template <Backend B, class T>
+void generalized_to_standard(comm::CommunicatorGrid& grid, blas::Uplo uplo, Matrix<T, Device::GPU>& mat_a,
+                             Matrix<T, Device::GPU>& mat_b) {
+  static_assert(B == Backend::GPU, "this library has no CPU backend");
+  if (uplo != mat_a.uplo() || uplo != mat_b.uplo())
+    dlaf::internal::fail("uplo of the call equals the uplo the device matrices were created with");
+  if (grid.context() != mat_a.context() || grid.context() != mat_b.context())
+    dlaf::internal::fail("matrix::equal_process_grid(mat_a, grid)");
+  if (dlaf_mi355x_generalized_to_standard_device(mat_a.handle(), mat_b.handle()) != 0)
+    dlaf::internal::fail("generalized_to_standard");
+}
 template <Backend B, class T>
 void generalized_to_standard(blas::Uplo uplo, Matrix<T, Device::CPU>& mat_a, Matrix<T, Device::CPU>& mat_b) {
   comm::CommunicatorGrid grid = comm::CommunicatorGrid::single();

@@ -61,6 +61,7 @@ def _build_miniapp(MINI_SRC, exe, mpi):
 def test_miniapp_compiles():
     assert os.path.exists(build_miniapp())
     assert os.path.exists(build_miniapp(name="miniapp_triangular_solver"))
+    assert os.path.exists(build_miniapp(name="miniapp_gen_to_std"))
 
 
 def check_miniapp_output(out, nruns, nchecks):
@@ -111,3 +112,18 @@ def test_miniapp_triangular_solver():
                           flags=re.M)) == 2, r.stdout
     resid = float(re.search(r"corner: ([0-9.e+-]+)", r.stdout).group(1))
     assert resid < 1e-11, r.stdout
+
+
+@pytest.mark.gpu
+def test_miniapp_gen_to_std():
+    """miniapp_gen_to_std.cpp: the reference's options and result lines; both operands resident on the device."""
+    import re
+    exe = build_miniapp(name="miniapp_gen_to_std")
+    for tp, uplo in (("d", "L"), ("z", "U")):
+        r = subprocess.run([exe, "--matrix-size", "1500", "--block-size", "128", "--type", tp, "--uplo", uplo, "--nruns", "2",
+                            "--csv"], cwd=ROOT, capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, DLAF_MI355X_DEVICE="0"))
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        assert len(re.findall(r"^\[\d+\] [0-9.e+-]+s [0-9.e+-]+GFlop/s %s%s \(1500, 1500\) \(128, 128\) \(1, 1\) 1 GPU" % (tp, uplo),
+                              r.stdout, flags=re.M)) == 2, r.stdout
+        assert r.stdout.count("CSVData-2, run, ") == 2, r.stdout
