@@ -31,13 +31,20 @@ struct CoopCfg {
   using R = real_t<T>;
   static constexpr bool CX = TypeInfo<T>::is_complex;
   static constexpr int NPL = CX ? 2 : 1;
-  // operand images [k][64 + pad]; complex<double> has no room for the pad in 160 KiB of LDS
-  static constexpr int PAD = (CX && sizeof(R) == 8) ? 0 : 16;
-  static constexpr int LD = kCB + PAD;
-  static constexpr int IMG = kCB * LD;              // one plane of one operand
-  static constexpr int OPERANDS = 2 * NPL * IMG;    // A and B images
-  static constexpr int ELEMS = OPERANDS > diag_lds_elems<T>() ? OPERANDS : diag_lds_elems<T>();
+  // complex<double>: the footprint has to stay below 96 KiB (160 KiB per CU minus the 64 KiB of a bulk-update
+  // workgroup) or no strip of a complex tile ever finds a CU while a persistent bulk launch is running.  REGA: the
+  // row operand of the MFMAs lives in registers (straight from global memory for the solve, the accumulators of
+  // the solve fed back for the updates: f64 accumulator register v of lane group g is exactly the k index the
+  // next MFMA wants), so only ONE operand image is staged; the diagonal step packs W into L's planes.
+  static constexpr bool REGA = CX && sizeof(R) == 8;
+  static constexpr int PAD = 16;
+  static constexpr int LD = kCB + PAD;               // operand images [k][64 + pad]
+  static constexpr int IMG = kCB * LD;               // one plane of one operand
+  static constexpr int OPERANDS = (REGA ? 1 : 2) * NPL * IMG;
+  static constexpr int DIAG = diag_lds_elems<T, REGA>();
+  static constexpr int ELEMS = OPERANDS > DIAG ? OPERANDS : DIAG;
   static constexpr int LDS_BYTES = ELEMS * (int) sizeof(R);
+  static_assert(!REGA || LDS_BYTES <= 95 * 1024, "must fit beside one bulk-update workgroup");
 };
 
 constexpr unsigned kCoopFailed = 0x40000000u;
@@ -210,6 +217,31 @@ __device__ __forceinline__ void coop_mma64(const real_t<T>* A, const real_t<T>* 
   }
 }
 
+// the same with the row operand in registers: a_re[k4] / a_im[k4] = A[m = wave*16 + c][k = 4 k4 + g]; the
+// accumulators are NOT cleared (the caller preloads them, e.g. with the block the product is subtracted from)
+template <class T>
+__device__ __forceinline__ void coop_mma64_rega(const real_t<T> (&a_re)[16], const real_t<T> (&a_im)[16],
+                                                const real_t<T>* B, typename Mma<real_t<T>>::acc_t (&re)[4],
+                                                typename Mma<real_t<T>>::acc_t (&im)[4]) {
+  using C = CoopCfg<T>;
+  using R = real_t<T>;
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+  for (int k4 = 0; k4 < kCB / 4; ++k4) {
+    const int kk = 4 * k4 + g;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const R b_re = B[kk * C::LD + j * 16 + c];
+      const R b_im = B[C::IMG + kk * C::LD + j * 16 + c];
+      re[j] = Mma<R>::mma(b_re, a_re[k4], re[j]);
+      re[j] = Mma<R>::mma(b_im, a_im[k4], re[j]);
+      im[j] = Mma<R>::mma(b_re, a_im[k4], im[j]);
+      im[j] = Mma<R>::mma(b_im, -a_re[k4], im[j]);
+    }
+  }
+}
+
 template <class T>
 __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__ tile, int ld, int kb,
                                                                   T* __restrict__ winv, int* info, int info_base,
@@ -236,7 +268,7 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
     return;
 
   R* Aimg = lds;
-  R* Bimg = lds + C::NPL * C::IMG;
+  R* Bimg = C::REGA ? lds : lds + C::NPL * C::IMG;
 
   for (int j = 0; j < s; ++j) {
     const int jb = kCB;  // every block column left of my diagonal block is full
@@ -249,6 +281,102 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
     }
     // ---- X_s = A(s,j) * inv(L_jj)^H ----------------------------------------------------------------
     T* Asj = tile + (long) kCB * s + (long) kCB * j * ld;
+    if constexpr (C::REGA) {
+      // addresses = (uniform base, scalar registers) + (one 32-bit lane offset): the operand element of lane (g, c)
+      // for k = 4 k4 + g and its accumulator element for n = 16 jt + 4 v + g share the lane part m + g ld
+      auto at = [](T* base, unsigned byte_off) {
+        return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off);
+      };
+      const int wv = __builtin_amdgcn_readfirstlane(wave);
+      const int m = wv * 16 + c;
+      const unsigned lane_off = (unsigned) sizeof(T) * (unsigned) (m + g * ld);
+      const unsigned img_off = (unsigned) sizeof(T) * (unsigned) ((t & 63) + (t >> 6) * ld);  // image element (m, k) of thread t
+      const bool m_ok = m < rows_s;
+      // B image [k][m] <- 64 columns of a global block with `rows` valid rows (column stride gld), in two halves
+      auto load_b = [&](T* gsrc, int gld, unsigned goff, int rows) {
+        const bool ok = (t & 63) < rows;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          T regs[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            regs[q] = ok ? *at(gsrc + (long) (4 * (8 * h + q)) * gld, goff) : zero_el<T>();
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int k = (t >> 6) + 4 * (8 * h + q);
+            Bimg[k * C::LD + (t & 63)] = re_of(regs[q]);
+            Bimg[C::IMG + k * C::LD + (t & 63)] = im_of(regs[q]);
+          }
+        }
+      };
+      R a_re[16], a_im[16];
+#pragma unroll
+      for (int k4 = 0; k4 < 16; ++k4) {
+        const T el = m_ok ? *at(Asj + (long) (4 * k4) * ld, lane_off) : zero_el<T>();
+        a_re[k4] = re_of(el);
+        a_im[k4] = im_of(el);
+      }
+      load_b(winv + (long) j * kCB * kCB, kCB, (unsigned) sizeof(T) * (unsigned) ((t & 63) + (t >> 6) * kCB), kCB);
+      __syncthreads();
+      acc_t xre[4], xim[4];
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        xre[jt] = acc_t{0, 0, 0, 0};
+        xim[jt] = acc_t{0, 0, 0, 0};
+      }
+      coop_mma64_rega<T>(a_re, a_im, Bimg, xre, xim);
+      // X_s(m, n = 16 jt + g + 4 v) = operand element k4 = 4 jt + v of the updates below, NEGATED there so that
+      // the MFMAs accumulate C - X_s X_c^H on top of the preloaded C block
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          if (m_ok)
+            store_wt(at(Asj + (long) (16 * jt + 4 * v) * ld, lane_off), make_el<T>(xre[jt][v], xim[jt][v]));
+          a_re[4 * jt + v] = -xre[jt][v];
+          a_im[4 * jt + v] = -xim[jt][v];
+        }
+      coop_publish(&xflag[(long) j * G + s], 1u, false);
+      if (s - j - 1 > 0 && !coop_wait_all(&xflag[(long) j * G + j + 1], s - j - 1, &wait_slot, spin_limit)) {
+        if (t == 0)
+          atomicCAS(info, 0, kInfoSchedulingFailure);
+        return;
+      }
+      // ---- A(s,c) -= X_s * X_c^H for c = j+1 .. s: the C block is loaded INTO the accumulators ---------
+#pragma unroll 1
+      for (int cc = j + 1; cc <= s; ++cc) {
+        const int rows_c = min(kCB, kb - kCB * cc);
+        T* Csc = tile + (long) kCB * s + (long) kCB * cc * ld;
+        const bool diag = (cc == s);
+        acc_t ure[4], uim[4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int n = jt * 16 + 4 * v + g;
+            const T el = (m_ok && n < rows_c && (!diag || m >= n)) ? *at(Csc + (long) (16 * jt + 4 * v) * ld, lane_off)
+                                                                   : zero_el<T>();
+            ure[jt][v] = re_of(el);
+            uim[jt][v] = im_of(el);
+          }
+        __syncthreads();  // every wave is done with the previous B image (winv, or X of the previous block)
+        // (my own X_s is the column operand of the diagonal block: read back like any other strip's)
+        load_b(tile + (long) kCB * cc + (long) kCB * j * ld, ld, img_off, rows_c);
+        __syncthreads();
+        coop_mma64_rega<T>(a_re, a_im, Bimg, ure, uim);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int n = jt * 16 + 4 * v + g;
+            if (m_ok && n < rows_c && (!diag || m >= n))
+              *at(Csc + (long) (16 * jt + 4 * v) * ld, lane_off) =
+                  make_el<T>(ure[jt][v], (diag && m == n) ? R(0) : uim[jt][v]);
+          }
+      }
+      __syncthreads();  // the next step (or the diagonal phase) rewrites the image
+      continue;
+    }
     coop_load_image<T>(Aimg, Asj, ld, rows_s, jb);
     coop_load_image<T>(Bimg, winv + (long) j * kCB * kCB, kCB, kCB, kCB);
     __syncthreads();
@@ -328,9 +456,10 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
 
   // ---- j == s: my diagonal block is final ---------------------------------------------------------
   {
+    constexpr bool PACK = C::REGA;
     R* Lre = lds;
     R* Lim = Lre + kPD * kPDLd;
-    R* Wre = Lre + C::NPL * kPD * kPDLd;
+    R* Wre = PACK ? Lre : Lre + C::NPL * kPD * kPDLd;
     R* Wim = Wre + kPD * kPDLd;
     T* Ass = tile + (long) kCB * s + (long) kCB * s * ld;
     const int jb = rows_s;
@@ -357,13 +486,15 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
         Lre[cl * kPDLd + r] = re;
         if constexpr (C::CX)
           Lim[cl * kPDLd + r] = (r == cl) ? R(0) : imv;
-        Wre[cl * kPDLd + r] = 0;
-        if constexpr (C::CX)
-          Wim[cl * kPDLd + r] = 0;
+        if constexpr (!PACK) {
+          Wre[cl * kPDLd + r] = 0;
+          if constexpr (C::CX)
+            Wim[cl * kPDLd + r] = 0;
+        }
       }
     }
     __syncthreads();
-    const int failed = diag_factor_invert<T>(Lre, Lim, Wre, Wim, jb, 1, &fail_col);
+    const int failed = diag_factor_invert<T, PACK>(Lre, Lim, Wre, Wim, jb, 1, &fail_col);
     if (failed >= 0) {
       if (t == 0)
         atomicCAS(info, 0, info_base + kCB * s + failed + 1);
@@ -381,9 +512,9 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
       }
       R wre = 0, wim = 0;
       if (rr < jb && cl < jb) {
-        wre = Wre[cl * kPDLd + rr];
+        wre = diag_w_get<PACK>(Wre, PACK ? diag_wd_re<T, PACK>(Wre) : nullptr, rr, cl);
         if constexpr (C::CX)
-          wim = Wim[cl * kPDLd + rr];
+          wim = diag_w_get<PACK>(Wim, PACK ? diag_wd_im<T, PACK>(Wre) : nullptr, rr, cl);
       }
       store_wt(&Ws[rr + (long) cl * kPD], make_el<T>(wre, wim));
     }

@@ -20,17 +20,55 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
 }
 
 
-// LDS image sizes (elements of R): L and W planes + the inversion scratch
-template <class T>
+// LDS image sizes (elements of R): L and W planes + the inversion scratch.
+// PACK: W shares the planes of L -- W(i,j), i > j, sits at the TRANSPOSED position (column i, row j: the strictly
+// upper triangle, which L does not use), its diagonal in 64 extra elements per plane behind the scratch.  Halves
+// the footprint: complex<double> 145 KiB -> 80 KiB, which is what lets the cooperative POTRF of a complex tile run
+// beside a workgroup of the bulk update (64 KiB) on the same CU.
+template <class T, bool PACK = false>
 constexpr int diag_lds_elems() {
-  return (TypeInfo<T>::is_complex ? 4 : 2) * kPD * kPDLd + (TypeInfo<T>::is_complex ? 2 : 1) * 3 * kPB * kPB;
+  constexpr int planes = TypeInfo<T>::is_complex ? 2 : 1;
+  return (PACK ? planes : 2 * planes) * kPD * kPDLd + planes * 3 * kPB * kPB + (PACK ? planes * kPD : 0);
 }
 
-// L image in (Lre, Lim) ([col][row], ld kPDLd; lower triangle, identity beyond jb), W planes zeroed.
+// W(i, j) of the inverse under construction; plane = the re or im plane of W (== that of L when PACK), wd = the
+// packed diagonal of the same plane
+template <bool PACK, class R>
+__device__ __forceinline__ R diag_w_get(const R* plane, const R* wd, int i, int j) {
+  if constexpr (!PACK)
+    return plane[j * kPDLd + i];
+  else
+    return i > j ? plane[i * kPDLd + j] : (i == j ? wd[i] : R(0));
+}
+template <bool PACK, class R>
+__device__ __forceinline__ void diag_w_set(R* plane, R* wd, int i, int j, R v) {
+  if constexpr (!PACK) {
+    plane[j * kPDLd + i] = v;
+  }
+  else {
+    if (i > j)
+      plane[i * kPDLd + j] = v;
+    else if (i == j)
+      wd[i] = v;
+  }
+}
+
+// L image in (Lre, Lim) ([col][row], ld kPDLd; lower triangle, identity beyond jb), W planes zeroed (PACK: Wre ==
+// Lre, Wim == Lim, nothing to zero; read the result with diag_w_get and diag_wd_re / diag_wd_im).
 // Factors (when factor != 0) and inverts in place.  Every thread of the workgroup must call it.
 // Returns -1, or the failing column; *fail_col is a workgroup-shared int the caller set to -1 before
 // the preceding barrier.
-template <class T>
+template <class T, bool PACK>
+__device__ __forceinline__ real_t<T>* diag_wd_re(real_t<T>* Wre) {
+  constexpr int planes = TypeInfo<T>::is_complex ? 2 : 1;
+  return Wre + planes * kPD * kPDLd + planes * 3 * kPB * kPB;  // behind the T scratch
+}
+template <class T, bool PACK>
+__device__ __forceinline__ real_t<T>* diag_wd_im(real_t<T>* Wre) {
+  return diag_wd_re<T, PACK>(Wre) + kPD;
+}
+
+template <class T, bool PACK = false>
 __device__ __forceinline__ int diag_factor_invert(real_t<T>* Lre, real_t<T>* Lim, real_t<T>* Wre, real_t<T>* Wim,
                                                   int jb, int factor, int* fail_col) {
   using R = real_t<T>;
@@ -147,6 +185,8 @@ __device__ __forceinline__ int diag_factor_invert(real_t<T>* Lre, real_t<T>* Lim
   }
 
   // ---- W = inv(L) -----------------------------------------------------------------------------------
+  R* const wd_re = PACK ? diag_wd_re<T, PACK>(Wre) : nullptr;
+  R* const wd_im = PACK ? diag_wd_im<T, PACK>(Wre) : nullptr;
   // (a) diagonal 16x16 blocks: wave w inverts block w; lane c < 16 owns column c of the block
   {
     const int b0 = wave * kPB;
@@ -193,9 +233,9 @@ __device__ __forceinline__ int diag_factor_invert(real_t<T>* Lre, real_t<T>* Lim
       }
 #pragma unroll
       for (int i = 0; i < kPB; ++i) {
-        Wre[(b0 + c) * kPDLd + b0 + i] = wre[i];
+        diag_w_set<PACK>(Wre, wd_re, b0 + i, b0 + c, wre[i]);
         if constexpr (CX)
-          Wim[(b0 + c) * kPDLd + b0 + i] = wim[i];
+          diag_w_set<PACK>(Wim, wd_im, b0 + i, b0 + c, wim[i]);
       }
     }
   }
@@ -214,10 +254,10 @@ __device__ __forceinline__ int diag_factor_invert(real_t<T>* Lre, real_t<T>* Lim
       R sre = 0, sim = 0;
       for (int k = c0; k < r0; ++k) {  // k runs over columns of L(i, j..i-1) = rows of W(j..i-1, j)
         const R l_re = Lre[k * kPDLd + r0 + ti];
-        const R w_re = Wre[(c0 + tj) * kPDLd + k];
+        const R w_re = diag_w_get<PACK>(Wre, wd_re, k, c0 + tj);
         if constexpr (CX) {
           const R l_im = Lim[k * kPDLd + r0 + ti];
-          const R w_im = Wim[(c0 + tj) * kPDLd + k];
+          const R w_im = diag_w_get<PACK>(Wim, wd_im, k, c0 + tj);
           sre += l_re * w_re - l_im * w_im;
           sim += l_re * w_im + l_im * w_re;
         }
@@ -236,10 +276,10 @@ __device__ __forceinline__ int diag_factor_invert(real_t<T>* Lre, real_t<T>* Lim
       R sre = 0, sim = 0;
 #pragma unroll
       for (int k = 0; k < kPB; ++k) {
-        const R w_re = Wre[(r0 + k) * kPDLd + r0 + ti];  // W(i,i)[ti][k]
+        const R w_re = diag_w_get<PACK>(Wre, wd_re, r0 + ti, r0 + k);  // W(i,i)[ti][k]
         const R t_re = Tre[j * kPB * kPB + tj * kPB + k];
         if constexpr (CX) {
-          const R w_im = Wim[(r0 + k) * kPDLd + r0 + ti];
+          const R w_im = diag_w_get<PACK>(Wim, wd_im, r0 + ti, r0 + k);
           const R t_im = Tim[j * kPB * kPB + tj * kPB + k];
           sre += w_re * t_re - w_im * t_im;
           sim += w_re * t_im + w_im * t_re;
@@ -248,9 +288,9 @@ __device__ __forceinline__ int diag_factor_invert(real_t<T>* Lre, real_t<T>* Lim
           sre += w_re * t_re;
         }
       }
-      Wre[(c0 + tj) * kPDLd + r0 + ti] = -sre;
+      diag_w_set<PACK>(Wre, wd_re, r0 + ti, c0 + tj, -sre);
       if constexpr (CX)
-        Wim[(c0 + tj) * kPDLd + r0 + ti] = -sim;
+        diag_w_set<PACK>(Wim, wd_im, r0 + ti, c0 + tj, -sim);
     }
     __syncthreads();
   }
