@@ -88,6 +88,10 @@ struct Mma<double> {
   static __device__ __forceinline__ acc_t mma(double aop, double bop, acc_t c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, c, 0, 0, 0);
   }
+  // c - aop * bop: for the f64 MFMAs the BLGP field holds negate bits (neg:[1,0,0] = the first operand)
+  static __device__ __forceinline__ acc_t mma_neg(double aop, double bop, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, c, 0, 0, 1);
+  }
   // index along i (the 16 "Aop rows") that register v of lane-group g = l>>4 holds
   static __device__ __forceinline__ int irow(int g, int v) { return g + 4 * v; }
 };
@@ -97,6 +101,9 @@ struct Mma<float> {
   typedef float acc_t __attribute__((ext_vector_type(4)));
   static __device__ __forceinline__ acc_t mma(float aop, float bop, acc_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(aop, bop, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ acc_t mma_neg(float aop, float bop, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(-aop, bop, c, 0, 0, 0);  // (BLGP is a lane swizzle for f32)
   }
   static __device__ __forceinline__ int irow(int g, int v) { return 4 * g + v; }
 };

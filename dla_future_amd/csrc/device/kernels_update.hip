@@ -68,12 +68,13 @@ struct UpdateMap {
   unsigned* counters;  // persist: 8 (per workgroup-id-mod-8, i.e. per XCD) or 1 dequeue heads, zeroed per launch;
                        // counters[8 + q]: work items of queue q that are finished (lockstep pacing)
   int lockstep;        // persist: the workgroups of a queue start their items in rounds (see update_kernel)
+  unsigned kphase_ticks;  // persist: wall-clock ticks per K slab of a block (0: every block starts at slab 0)
 };
 
 // One work item = one BM x BN block of one tile.  Returns early for blocks outside the domain.
 template <class T, bool VEC, bool UTAIL = false>
 __device__ __forceinline__ void update_block(const UpdateArgs<T>& p, const UpdateMap& mp, long w,
-                                             real_t<T>* __restrict__ lds) {
+                                             real_t<T>* __restrict__ lds, int s0 = 0) {
   using Cfg = typename UpdateCfg<T>::type;
   using R = real_t<T>;
 
@@ -172,9 +173,60 @@ __device__ __forceinline__ void update_block(const UpdateArgs<T>& p, const Updat
 
   const bool full = (mrows == Cfg::BM) && (ncols == Cfg::BN) && (p.K % Cfg::BK == 0) && (p.K1 % Cfg::BK == 0);
   Acc<Cfg> acc;
+#ifndef DLAF_UPD_PRELOAD
+#define DLAF_UPD_PRELOAD 1
+#endif
+  if constexpr (DLAF_UPD_PRELOAD && Cfg::PAIRED && !Cfg::CX && sizeof(R) == 8 && VEC && !UTAIL) {
+    // Interior blocks (fp64 fast path): C is loaded INTO the accumulators before the K loop -- the loads travel
+    // with the first slabs, whose arrival the loop waits for anyway -- and the MFMAs subtract (neg:[1,0,0]), so
+    // the block ends with plain stores instead of 16 load -> wait -> subtract -> store round trips.  A/B on one
+    // MI355X (tools/run_ab_preload.sh): one-block-per-workgroup launches 66.3 -> 67.8 TFlop/s (N = 49152, K =
+    // 1024); the persistent bulk launches LOSE 3 % (66.9 -> 65.0; nb = 512: 61.2 -> 57.4 -- the stores of block i
+    // and the C loads of block i+1 queue ahead of its first slabs), so the bulk instantiation keeps the old form.
+    const bool unmasked = full && !(diag && m0 < n0 + ncols - 1);
+    if (unmasked && ((p.ldc * (long) sizeof(T)) % 16 == 0) && (reinterpret_cast<uintptr_t>(C) % 16 == 0)) {
+      typedef R r2 __attribute__((ext_vector_type(2)));
+      // address = uniform base (scalar registers: block, wave tile, accumulator column) + ONE 32-bit lane offset:
+      // 32 pointers kept live across the K loop would cost 64 registers
+      const int lane_ = threadIdx.x & 63, wave_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+      const int wm_ = wave_ % Cfg::WAVES_M, wn_ = wave_ / Cfg::WAVES_M;
+      const int g_ = lane_ >> 4, c_ = lane_ & 15;
+      const unsigned lane_off = (unsigned) sizeof(T) * (unsigned) (2 * c_ + 2 * g_ * (int) p.ldc);
+      T* Cw = C + wm_ * Cfg::WM + (long) (wn_ * Cfg::WN) * p.ldc;
+      auto at = [](T* base, unsigned byte_off) {
+        return reinterpret_cast<r2*>(reinterpret_cast<char*>(base) + byte_off);
+      };
+      static_assert(Cfg::TN % 2 == 0, "paired accumulator columns");
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          T* col = Cw + (long) ((j >> 1) * 32 + 8 * v + (j & 1)) * p.ldc;  // acc_n(j, g, v) minus the lane part 2 g
+#pragma unroll
+          for (int q = 0; q < Cfg::TM / 2; ++q) {
+            const r2 cv = *at(col + q * 32, lane_off);
+            acc.re[2 * q][j][v] = cv[0];
+            acc.re[2 * q + 1][j][v] = cv[1];
+          }
+        }
+      gemm_nt_block<Cfg, T, VEC, false, UTAIL, true>(A, DLAF_LDA_X, mrows, B, DLAF_LDB_X, ncols, p.K, lds, acc, K1, A2,
+                                                     B2);
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          T* col = Cw + (long) ((j >> 1) * 32 + 8 * v + (j & 1)) * p.ldc;
+#pragma unroll
+          for (int q = 0; q < Cfg::TM / 2; ++q)
+            *at(col + q * 32, lane_off) = r2{acc.re[2 * q][j][v], acc.re[2 * q + 1][j][v]};
+        }
+      return;
+    }
+  }
   acc.clear();
   if (full)
-    gemm_nt_block<Cfg, T, VEC, false, UTAIL>(A, DLAF_LDA_X, mrows, B, DLAF_LDB_X, ncols, p.K, lds, acc, K1, A2, B2);
+    gemm_nt_block<Cfg, T, VEC, false, UTAIL>(A, DLAF_LDA_X, mrows, B, DLAF_LDB_X, ncols, p.K, lds, acc, K1, A2, B2,
+                                             s0);
   else
     gemm_nt_block<Cfg, T, false, true>(A, p.lda, mrows, B, ldb, ncols, p.K, lds, acc, K1, A2, B2);
 
@@ -336,11 +388,26 @@ __global__ __launch_bounds__(UpdateCfg<T>::type::THREADS, UpdateCfg<T>::min_wave
   // 50 % (measured: TCC hit 48 %, 95 GB fetched per launch for 158 GB requested at N = 49152).  Pure pacing: no
   // data depends on it, the spin is bounded.
   const unsigned W = gridDim.x / nq;
+  // K-phase alignment: the sum over k of a block may start anywhere, so every block starts at the slab "the wall
+  // clock is at" -- (ticks / ticks-per-slab) mod slabs -- and wraps around.  Blocks of an XCD that stream the same
+  // operand strips are then at (nearly) the same k whenever they started, instead of wherever their start time
+  // left them: a slab one of them fetched is still in the 4 MiB L2 when the others ask for it.  No waiting, no
+  // communication; the price is a summation order that depends on the start time (results reproducible to rounding,
+  // not bitwise).  Measured on MI355X (tools/run_ab_kphase.sh, profiles/r02_update_kernel_kphase_*): it does what it
+  // was built for -- L2 hit rate 43 % -> 61 %, fabric fetch 542 -> 370 GB per three launches -- and the kernel is
+  // exactly as fast as before (67.9 vs 67.9 TFlop/s alone, 67.3 vs 67.3 in the factorization): a slab is 256 lines,
+  // the barrier waits for the slowest of them, and at 61 % hits every slab still has misses.  So: opt-in
+  // (DLAF_MI355X_KPHASE=1), default = the fixed summation order.
+  __shared__ int next_s0;
+  const int nslab = p.K / UpdateCfg<T>::type::BK;
   for (;;) {
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
       next_item = atomicAdd(&mp.counters[q], 1u);
+      next_s0 = (mp.kphase_ticks != 0 && nslab > 1) ? (int) ((wall_clock64() / mp.kphase_ticks) % (unsigned) nslab) : 0;
+    }
     __syncthreads();
     const long i = next_item;
+    const int s0 = next_s0;
     __syncthreads();
     if (i >= per_q)
       break;
@@ -353,7 +420,7 @@ __global__ __launch_bounds__(UpdateCfg<T>::type::THREADS, UpdateCfg<T>::min_wave
       }
       __syncthreads();
     }
-    update_block<T, VEC, ROLE == 0>(p, mp, (long) q * per_q + i, lds);
+    update_block<T, VEC, ROLE == 0>(p, mp, (long) q * per_q + i, lds, s0);
     if (mp.lockstep && threadIdx.x == 0)
       __hip_atomic_fetch_add(&mp.counters[8 + q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -366,6 +433,36 @@ static bool update_lockstep() {
     return e ? std::atoi(e) != 0 : false;  // measured: 56.4 vs 66.6 TFlop/s -- the rounds wait for their slowest block
   }();
   return on;
+}
+
+// Wall-clock ticks (hipDeviceAttributeWallClockRate, the clock wall_clock64() reads) one K slab of one block
+// takes when `resident` workgroups share the GPU at the bulk kernel's in-situ rate; 0 = K-phase alignment off
+// (the default; DLAF_MI355X_KPHASE=1 turns it on).  DLAF_MI355X_KPHASE_RATE overrides the assumed rate (TFlop/s).  An error of 5 % in the
+// rate misplaces two blocks by at most 5 % of the offset between their start times -- a few slabs.
+template <class T>
+static unsigned kphase_ticks(int resident) {
+  using Cfg = typename UpdateCfg<T>::type;
+  static const double rate = [] {
+    const char* on = std::getenv("DLAF_MI355X_KPHASE");
+    if (on == nullptr || std::atoi(on) == 0)
+      return 0.0;  // default off: see update_kernel
+    if (const char* e = std::getenv("DLAF_MI355X_KPHASE_RATE"))
+      return std::atof(e) * 1e12;
+    return (sizeof(real_t<T>) == 8 ? 66.5e12 : 120e12);
+  }();
+  static const double khz = [] {
+    int dev = 0, v = 0;
+    (void) hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeWallClockRate, dev) != hipSuccess || v <= 0)
+      v = 100000;
+    return (double) v;
+  }();
+  if (rate <= 0 || resident <= 0)
+    return 0;
+  const double flops = (TypeInfo<T>::is_complex ? 8.0 : 2.0) * Cfg::BM * Cfg::BN * Cfg::BK;
+  const double seconds = flops / (rate / resident);
+  const double ticks = seconds * khz * 1e3;
+  return ticks < 1 ? 1u : (unsigned) (ticks + 0.5);
 }
 
 template <class T>
@@ -423,6 +520,7 @@ void launch_update(const UpdateArgs<T>& a, hipStream_t stream, int role, long ma
   long grid = mp.total;
   mp.persist = 0;
   mp.lockstep = 0;
+  mp.kphase_ticks = 0;
   mp.counters = nullptr;
   if (max_blocks > 0 && counters != nullptr && mp.total > max_blocks) {
     grid = mp.xcd ? (max_blocks / 8) * 8 : max_blocks;  // equal number of workgroups per XCD range
@@ -431,6 +529,7 @@ void launch_update(const UpdateArgs<T>& a, hipStream_t stream, int role, long ma
     mp.persist = 1;
     mp.counters = counters;
     mp.lockstep = update_lockstep() ? 1 : 0;
+    mp.kphase_ticks = kphase_ticks<T>((int) (grid));
     (void) hipMemsetAsync(counters, 0, 16 * sizeof(unsigned), stream);
   }
   const bool vec = aligned16<T>(a.a, a.lda) && aligned16<T>(a.a, a.a_ts) && aligned16<T>(a.b, a.ldb) &&

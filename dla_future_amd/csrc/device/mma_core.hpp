@@ -83,7 +83,8 @@ struct NoHook {
 // direct-to-LDS pipeline issues its loads of a later slab there, one at a time in the shadow of the MFMAs,
 // instead of as one block at the head of the iteration (8 x global_load_lds back to back keep the wave from
 // issuing MFMAs for ~1k cycles per slab; measured with in-kernel stamps, tools/update_bench.hip)
-template <class Cfg, class Hook = NoHook>
+// NEG: acc -= A B^H instead of += (the accumulators were preloaded with the block the product is subtracted from)
+template <class Cfg, bool NEG = false, class Hook = NoHook>
 __device__ __forceinline__ void mma_slab(const typename Cfg::R* __restrict__ As,
                                          const typename Cfg::R* __restrict__ Bs, Acc<Cfg>& acc, int wm,
                                          int wn, int lane, Hook&& hook = Hook{}) {
@@ -143,12 +144,22 @@ __device__ __forceinline__ void mma_slab(const typename Cfg::R* __restrict__ As,
 #pragma unroll
       for (int i = 0; i < Cfg::TM; ++i) {
         // D[i' = n][j' = m]: Aop <- B panel fragment, Bop <- A panel fragment
-        acc.re[i][j] = Mma<R>::mma(b_re[j], a_re[i], acc.re[i][j]);
-        if constexpr (Cfg::CX) {
-          // (ar + i ai)(br - i bi) = (ar br + ai bi) + i (ai br - ar bi)
-          acc.re[i][j] = Mma<R>::mma(b_im[j], a_im[i], acc.re[i][j]);
-          acc.im[i][j] = Mma<R>::mma(b_re[j], a_im[i], acc.im[i][j]);
-          acc.im[i][j] = Mma<R>::mma(b_im[j], -a_re[i], acc.im[i][j]);
+        if constexpr (!NEG) {
+          acc.re[i][j] = Mma<R>::mma(b_re[j], a_re[i], acc.re[i][j]);
+          if constexpr (Cfg::CX) {
+            // (ar + i ai)(br - i bi) = (ar br + ai bi) + i (ai br - ar bi)
+            acc.re[i][j] = Mma<R>::mma(b_im[j], a_im[i], acc.re[i][j]);
+            acc.im[i][j] = Mma<R>::mma(b_re[j], a_im[i], acc.im[i][j]);
+            acc.im[i][j] = Mma<R>::mma(b_im[j], -a_re[i], acc.im[i][j]);
+          }
+        }
+        else {
+          acc.re[i][j] = Mma<R>::mma_neg(b_re[j], a_re[i], acc.re[i][j]);
+          if constexpr (Cfg::CX) {
+            acc.re[i][j] = Mma<R>::mma_neg(b_im[j], a_im[i], acc.re[i][j]);
+            acc.im[i][j] = Mma<R>::mma_neg(b_re[j], a_im[i], acc.im[i][j]);
+            acc.im[i][j] = Mma<R>::mma(b_im[j], a_re[i], acc.im[i][j]);
+          }
         }
       }
     }
@@ -258,12 +269,12 @@ __device__ __forceinline__ void stage_glds_one(const T* __restrict__ A, long lda
 // no branch around the loads and one wait count.  Measured on the persistent bulk launches (fp64, 480 workgroups):
 // 65.7 -> 67.0 TFlop/s at K = 1024, 66.2 -> 67.4 at K = 2048; on one-block-per-workgroup launches it costs 8 %
 // (the drain delays the epilogue), so only the bulk instantiation of the update kernel asks for it.
-template <class Cfg, class T, bool VEC, bool EDGE, bool UTAIL = false>
+template <class Cfg, class T, bool VEC, bool EDGE, bool UTAIL = false, bool NEG = false>
 __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda, int mrows,
                                               const T* __restrict__ B, long ldb, int ncols, int K,
                                               typename Cfg::R* __restrict__ lds, Acc<Cfg>& acc, int K1 = 1 << 30,
                                               const T* __restrict__ A2 = nullptr,
-                                              const T* __restrict__ B2 = nullptr) {
+                                              const T* __restrict__ B2 = nullptr, int s0 = 0) {
   using R = typename Cfg::R;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -278,11 +289,17 @@ __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda,
     constexpr int ST = Cfg::STAGES;
     constexpr int LPS = Cfg::LPS;
     static_assert(LPS * (ST - 2) < 64, "vmcnt is a 6-bit counter");
+    // s0 (direct-to-LDS path): the slab the sum over k STARTS at; the loop walks s0, s0+1, .., nk-1, 0, .., s0-1.
+    // The order of the sum is free, and a caller that starts every block at "the slab the others are at right
+    // now" keeps the blocks that share operand strips at the same k -- see update_kernel.  0 <= s0 < nk.
 #pragma unroll
     for (int s = 0; s < ST - 1; ++s)
-      if (s < nk)
-        stage_glds<Cfg, T>(s * Cfg::BK < K1 ? A : A2, lda, s * Cfg::BK < K1 ? B : B2, ldb, s * Cfg::BK,
+      if (s < nk) {
+        int sl = s0 + s;
+        sl = sl >= nk ? sl - nk : sl;
+        stage_glds<Cfg, T>(sl * Cfg::BK < K1 ? A : A2, lda, sl * Cfg::BK < K1 ? B : B2, ldb, sl * Cfg::BK,
                            lds + s * Cfg::BUF_ELEMS, wave, lane);
+      }
     // slab 0 must be complete: everything but the younger (ST-2) slabs
     if (nk >= ST - 1)
       __builtin_amdgcn_s_waitcnt(0x0070 | ((LPS * (ST - 2)) & 0xF) | ((((LPS * (ST - 2)) >> 4) & 0x3) << 14));
@@ -315,12 +332,14 @@ __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda,
       const bool load = UTAIL || (kt + ST - 1 < nk);
 #endif
       // (one copy of the MFMA stream: `load` only guards the single instructions, a scalar branch each)
-      const int kn = min(kt + ST - 1, nk - 1) * Cfg::BK;
+      int sn = s0 + min(kt + ST - 1, nk - 1);
+      sn = sn >= nk ? sn - nk : sn;
+      const int kn = sn * Cfg::BK;
       const T* An = kn < K1 ? A : A2;
       const T* Bn = kn < K1 ? B : B2;
       R* nbuf = lds + nxt_i * Cfg::BUF_ELEMS;
       if constexpr (SPLIT) {
-        mma_slab<Cfg>(cur, cur + Cfg::A_ELEMS, acc, wm, wn, lane, [&](int p) {
+        mma_slab<Cfg, NEG>(cur, cur + Cfg::A_ELEMS, acc, wm, wn, lane, [&](int p) {
           // (p is a compile-time constant after unrolling: the chain folds to the one instruction of group p)
 #define DLAF_GLDS_AT(I)                                                                     \
   if (p == I) {                                                                           \
@@ -337,7 +356,7 @@ __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda,
       else {
         if (load)
           stage_glds<Cfg, T>(An, lda, Bn, ldb, kn, nbuf, wave, lane);
-        mma_slab<Cfg>(cur, cur + Cfg::A_ELEMS, acc, wm, wn, lane);
+        mma_slab<Cfg, NEG>(cur, cur + Cfg::A_ELEMS, acc, wm, wn, lane);
       }
       // slab kt+1 landed?  still in flight afterwards: the loads of slabs kt+2 .. kt+ST-1 (none in the tail)
       if (load)
@@ -388,7 +407,7 @@ __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda,
         stage_glds<Cfg, T>(kn < K1 ? A : A2, lda, kn < K1 ? B : B2, ldb, kn, lds + nxt_i * Cfg::BUF_ELEMS, wave, lane);
       }
 #endif
-      mma_slab<Cfg>(cur, cur + Cfg::A_ELEMS, acc, wm, wn, lane);
+      mma_slab<Cfg, NEG>(cur, cur + Cfg::A_ELEMS, acc, wm, wn, lane);
       // next slab (kt+1) landed?  loads still allowed in flight: those of slabs kt+2 .. kt+ST-1
       const int younger = min(ST - 2, max(0, nk - 2 - kt));
       if (younger == ST - 2)
@@ -425,7 +444,7 @@ __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda,
       sa.template load<EDGE>(kn < K1 ? A : A2, lda, kn, mrows, K, A2, K1);
       sb.template load<EDGE>(kn < K1 ? B : B2, ldb, kn, ncols, K, B2, K1);
     }
-    mma_slab<Cfg>(cur, cur + Cfg::A_ELEMS, acc, wm, wn, lane);
+    mma_slab<Cfg, NEG>(cur, cur + Cfg::A_ELEMS, acc, wm, wn, lane);
     if (more) {
       sa.store(nxt);
       sb.store(nxt + Cfg::A_ELEMS);
