@@ -105,7 +105,7 @@ __device__ __forceinline__ unsigned coop_wait(unsigned* word, unsigned target, u
     unsigned v;
     long spins = 0;
     while ((v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
-      __builtin_amdgcn_s_sleep(16);
+      __builtin_amdgcn_s_sleep(4);
       if (++spins > spin_limit) {
         v = 0xFFFFFFFFu;
         break;
@@ -130,7 +130,7 @@ __device__ __forceinline__ bool coop_wait_all(unsigned* words, int n, unsigned* 
   if ((int) threadIdx.x < n) {
     long spins = 0;
     while (__hip_atomic_load(&words[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-      __builtin_amdgcn_s_sleep(16);
+      __builtin_amdgcn_s_sleep(4);
       if (++spins > spin_limit) {
         *shared_slot = 0u;
         break;
@@ -272,6 +272,24 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
 
   for (int j = 0; j < s; ++j) {
     const int jb = kCB;  // every block column left of my diagonal block is full
+    // A(s,j) is final since my own update of step j-1: its loads travel while I wait for the owner of step j
+    T* const Asj_pre = tile + (long) kCB * s + (long) kCB * j * ld;
+    T pre_a[C::REGA ? 1 : kCoopPerThread];
+    real_t<T> pre_re[C::REGA ? 16 : 1], pre_im[C::REGA ? 16 : 1];
+    if constexpr (!C::REGA) {
+      coop_fetch<T>(pre_a, Asj_pre, ld, rows_s, jb);
+    }
+    else {
+      const int m = (t >> 6) * 16 + c;
+      const unsigned lane_off = (unsigned) sizeof(T) * (unsigned) (m + g * ld);
+#pragma unroll
+      for (int k4 = 0; k4 < 16; ++k4) {
+        const T el = m < rows_s ? *reinterpret_cast<const T*>(reinterpret_cast<const char*>(Asj_pre + (long) (4 * k4) * ld) + lane_off)
+                                : zero_el<T>();
+        pre_re[k4] = re_of(el);
+        pre_im[k4] = im_of(el);
+      }
+    }
     const unsigned f = coop_wait(&flag[j], 1u, &wait_slot, spin_limit);
     if (f != 1u) {
       // not positive definite (info already set by the owner), or the spin bound was hit
@@ -312,9 +330,8 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
       R a_re[16], a_im[16];
 #pragma unroll
       for (int k4 = 0; k4 < 16; ++k4) {
-        const T el = m_ok ? *at(Asj + (long) (4 * k4) * ld, lane_off) : zero_el<T>();
-        a_re[k4] = re_of(el);
-        a_im[k4] = im_of(el);
+        a_re[k4] = pre_re[k4];
+        a_im[k4] = pre_im[k4];
       }
       load_b(winv + (long) j * kCB * kCB, kCB, (unsigned) sizeof(T) * (unsigned) ((t & 63) + (t >> 6) * kCB), kCB);
       __syncthreads();
@@ -377,8 +394,12 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
       __syncthreads();  // the next step (or the diagonal phase) rewrites the image
       continue;
     }
-    coop_load_image<T>(Aimg, Asj, ld, rows_s, jb);
-    coop_load_image<T>(Bimg, winv + (long) j * kCB * kCB, kCB, kCB, kCB);
+    if constexpr (!C::REGA) {
+      T wreg[kCoopPerThread];
+      coop_fetch<T>(wreg, winv + (long) j * kCB * kCB, kCB, kCB, kCB);
+      coop_commit<T>(Aimg, pre_a);
+      coop_commit<T>(Bimg, wreg);
+    }
     __syncthreads();
     acc_t xre[4], xim[4];
     coop_mma64<T>(Aimg, Bimg, xre, xim);

@@ -20,6 +20,30 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
 }
 
 
+// sqrt(d) and 1 / sqrt(d) of a pivot (d > 0, far from the denormal and overflow ranges: pivots of a matrix that
+// got this far) from one v_rsq_f64 and coupled Newton steps -- the library sqrt followed by a division is twice
+// as long a dependency chain, and this chain is the critical path of the whole factorization (64 pivots per
+// diagonal block, strictly one after the other).  Both results are within an ulp or two of the exact values.
+__device__ __forceinline__ void pivot_sqrt(double d, double& sq, double& inv) {
+  const double r = __builtin_amdgcn_rsq(d);  // ~2^-26 relative
+  double g = d * r;                          // ~ sqrt(d)
+  double h = 0.5 * r;                        // ~ 1 / (2 sqrt(d))
+  double e = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, e, g);
+  h = __builtin_fma(h, e, h);
+  e = __builtin_fma(-g, g, d);               // residual of the square
+  g = __builtin_fma(e, h, g);
+  e = __builtin_fma(-h, g, 0.5);
+  h = __builtin_fma(h, e, h);
+  e = __builtin_fma(-g, g, d);
+  sq = __builtin_fma(e, h, g);
+  inv = h + h;
+}
+__device__ __forceinline__ void pivot_sqrt(float d, float& sq, float& inv) {
+  sq = sqrtf(d);
+  inv = 1.0f / sq;
+}
+
 // LDS image sizes (elements of R): L and W planes + the inversion scratch.
 // PACK: W shares the planes of L -- W(i,j), i > j, sits at the TRANSPOSED position (column i, row j: the strictly
 // upper triangle, which L does not use), its diagonal in 64 extra elements per plane behind the scratch.  Halves
@@ -125,6 +149,9 @@ __device__ __forceinline__ int diag_factor_invert(real_t<T>* Lre, real_t<T>* Lim
         aim[c] = CX ? Lim[(p0 + c) * kPDLd + r] : R(0);
       }
       int failed = -1;
+      // Branch-free in the lane dimension: every lane runs the same arithmetic on its row (rows above the pivot
+      // carry values nobody reads -- only r >= column is written back, only lanes below the pivot are broadcast),
+      // so the register arrays need no per-branch copies; the pivot's sqrt and reciprocal are wave-uniform.
 #pragma unroll
       for (int c = 0; c < kPB; ++c) {
         const int pr = p0 + c;  // pivot row == pivot column (global in the block)
@@ -134,31 +161,22 @@ __device__ __forceinline__ int diag_factor_invert(real_t<T>* Lre, real_t<T>* Lim
             failed = pr;
           }
           else {
-            const R sq = sqrt(d);
-            if (r == pr) {
-              are[c] = sq;
-              aim[c] = 0;
-            }
-            else if (r > pr) {
-              are[c] = are[c] / sq;
-              if constexpr (CX)
-                aim[c] = aim[c] / sq;
-            }
+            R sq, inv;
+            pivot_sqrt(d, sq, inv);
+            are[c] = (r == pr) ? sq : are[c] * inv;
+            if constexpr (CX)
+              aim[c] = (r == pr) ? R(0) : aim[c] * inv;
 #pragma unroll
             for (int j = c + 1; j < kPB; ++j) {
               // l_j = L[p0+j][pr]: held by lane p0+j in are[c]
               const R lj_re = lane_bcast(are[c], p0 + j);
-              R lj_im = 0;
-              if constexpr (CX)
-                lj_im = lane_bcast(aim[c], p0 + j);
-              if (r >= p0 + j) {
-                if constexpr (CX) {
-                  are[j] -= are[c] * lj_re + aim[c] * lj_im;
-                  aim[j] -= aim[c] * lj_re - are[c] * lj_im;
-                }
-                else {
-                  are[j] -= are[c] * lj_re;
-                }
+              if constexpr (CX) {
+                const R lj_im = lane_bcast(aim[c], p0 + j);
+                are[j] -= are[c] * lj_re + aim[c] * lj_im;
+                aim[j] -= aim[c] * lj_re - are[c] * lj_im;
+              }
+              else {
+                are[j] -= are[c] * lj_re;
               }
             }
           }

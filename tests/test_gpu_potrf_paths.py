@@ -51,3 +51,12 @@ def test_expired_wait_is_reported_not_hung():
     # the device is usable afterwards
     r = run_child(FACTOR % (ROOT, 2048, 512))
     assert r.returncode == 0 and "RESULT 0" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
+def test_kphase_alignment_opt_in():
+    """DLAF_MI355X_KPHASE=1: every block of the persistent bulk launches starts its k loop at the wall-clock phase
+    and wraps around (kernels_update.hip) -- another summation order, the same factor to rounding."""
+    r = run_child(FACTOR % (ROOT, 8192, 512), DLAF_MI355X_KPHASE="1")
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    _, info, ratio, bar = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1].split()
+    assert int(info) == 0 and float(ratio) <= float(bar), r.stdout
