@@ -377,18 +377,39 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
             uim[jt][v] = im_of(el);
           }
         __syncthreads();  // every wave is done with the previous B image (winv, or X of the previous block)
-        // (my own X_s is the column operand of the diagonal block: read back like any other strip's)
-        load_b(tile + (long) kCB * cc + (long) kCB * j * ld, ld, img_off, rows_c);
+        if (!diag) {
+          load_b(tile + (long) kCB * cc + (long) kCB * j * ld, ld, img_off, rows_c);
+        }
+        else {
+          // my own X_s is the column operand of the diagonal block: image [k][m] straight from the (negated)
+          // operand registers, no trip through memory
+#pragma unroll
+          for (int k4 = 0; k4 < 16; ++k4) {
+            Bimg[(4 * k4 + g) * C::LD + m] = -a_re[k4];
+            Bimg[C::IMG + (4 * k4 + g) * C::LD + m] = -a_im[k4];
+          }
+        }
         __syncthreads();
         coop_mma64_rega<T>(a_re, a_im, Bimg, ure, uim);
+        const bool to_lds = diag && (j == s - 1);  // (see the real-type path: straight into the L planes)
+        if (to_lds)
+          __syncthreads();
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
             const int n = jt * 16 + 4 * v + g;
-            if (m_ok && n < rows_c && (!diag || m >= n))
+            const bool in = (m_ok && n < rows_c && (!diag || m >= n));
+            if (to_lds) {
+              R* Lre = lds;
+              R* Lim = Lre + kPD * kPDLd;
+              Lre[n * kPDLd + m] = in ? ure[jt][v] : ((m == n && m >= rows_s) ? R(1) : R(0));
+              Lim[n * kPDLd + m] = (in && m != n) ? uim[jt][v] : R(0);
+            }
+            else if (in) {
               *at(Csc + (long) (16 * jt + 4 * v) * ld, lane_off) =
                   make_el<T>(ure[jt][v], (diag && m == n) ? R(0) : uim[jt][v]);
+            }
           }
       }
       __syncthreads();  // the next step (or the diagonal phase) rewrites the image
@@ -428,21 +449,25 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
     // types have no registers to spare for the X prefetch beside a co-resident bulk-update wave
     constexpr bool kPrefetch = !C::CX;
     T nextB[kPrefetch ? kCoopPerThread : 1];
+    // (the column operand of my own diagonal block is my own X_s: it is in LDS already)
     if constexpr (kPrefetch)
-      coop_fetch<T>(nextB, tile + (long) kCB * (j + 1) + (long) kCB * j * ld, ld, min(kCB, kb - kCB * (j + 1)), jb);
+      if (j + 1 < s)
+        coop_fetch<T>(nextB, tile + (long) kCB * (j + 1) + (long) kCB * j * ld, ld, min(kCB, kb - kCB * (j + 1)), jb);
     for (int cc = j + 1; cc <= s; ++cc) {
       const int rows_c = min(kCB, kb - kCB * cc);
-      if constexpr (kPrefetch)
-        coop_commit<T>(Bimg, nextB);
-      else
-        coop_load_image<T>(Bimg, tile + (long) kCB * cc + (long) kCB * j * ld, ld, rows_c, jb);
+      const bool diag = (cc == s);
+      if (!diag) {
+        if constexpr (kPrefetch)
+          coop_commit<T>(Bimg, nextB);
+        else
+          coop_load_image<T>(Bimg, tile + (long) kCB * cc + (long) kCB * j * ld, ld, rows_c, jb);
+      }
       __syncthreads();
       if constexpr (kPrefetch)
-        if (cc + 1 <= s)
+        if (cc + 1 < s)
           coop_fetch<T>(nextB, tile + (long) kCB * (cc + 1) + (long) kCB * j * ld, ld, min(kCB, kb - kCB * (cc + 1)),
                         jb);
       T* Csc = tile + (long) kCB * s + (long) kCB * cc * ld;
-      const bool diag = (cc == s);
       T cv[4][4];
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt)
@@ -452,20 +477,38 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
           cv[jt][v] = (m < rows_s && n < rows_c && (!diag || m >= n)) ? Csc[m + (long) n * ld] : zero_el<T>();
         }
       acc_t ure[4], uim[4];
-      coop_mma64<T>(Aimg, Bimg, ure, uim);
+      coop_mma64<T>(Aimg, diag ? Aimg : Bimg, ure, uim);
+      // The last update before my diagonal step (block (s,s) under column s-1) goes straight into the L planes of
+      // that step instead of to memory and back: two global round trips less on the critical path of the tile.
+      const bool to_lds = diag && (j == s - 1);
+      if (to_lds)
+        __syncthreads();  // the L / W planes alias the operand images: every wave is done reading them
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int m = wave * 16 + c, n = jt * 16 + Mma<R>::irow(g, v);
-          if (m < rows_s && n < rows_c && (!diag || m >= n)) {
-            T r = cv[jt][v];
+          const bool in = (m < rows_s && n < rows_c && (!diag || m >= n));
+          T r = cv[jt][v];
+          if constexpr (C::CX) {
+            r = T{r.re - ure[jt][v], (diag && m == n) ? R(0) : r.im - uim[jt][v]};
+          }
+          else {
+            r = r - ure[jt][v];
+          }
+          if (to_lds) {
+            R* Lre = lds;
+            R* Lim = Lre + kPD * kPDLd;
+            R* Wre = Lre + C::NPL * kPD * kPDLd;
+            R* Wim = Wre + kPD * kPDLd;
+            Lre[n * kPDLd + m] = in ? re_of(r) : ((m == n && m >= rows_s) ? R(1) : R(0));
+            Wre[n * kPDLd + m] = 0;
             if constexpr (C::CX) {
-              r = T{r.re - ure[jt][v], (diag && m == n) ? R(0) : r.im - uim[jt][v]};
+              Lim[n * kPDLd + m] = (in && m != n) ? im_of(r) : R(0);
+              Wim[n * kPDLd + m] = 0;
             }
-            else {
-              r = r - ure[jt][v];
-            }
+          }
+          else if (in) {
             Csc[m + (long) n * ld] = r;
           }
         }
@@ -486,10 +529,8 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
     const int jb = rows_s;
     if (t == 0)
       fail_col = -1;
-    // make sure my own updates of block (s,s) (plain stores of this workgroup) are complete
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    {
+    // s > 0: the last update of the loop above left the block in the L planes (and zeroed W)
+    if (s == 0) {
       T regs[kCoopPerThread];
 #pragma unroll
       for (int q = 0; q < kCoopPerThread; ++q) {
