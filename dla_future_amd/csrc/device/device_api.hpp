@@ -66,7 +66,7 @@ struct UpdateArgs {
 // must run beside the update.
 template <class T>
 void launch_update(const UpdateArgs<T>& args, hipStream_t stream, int role = 0, long max_blocks = 0,
-                   unsigned* counters = nullptr);
+                   unsigned* counters = nullptr, bool counters_are_zero = false);
 template <class T>
 int update_blocks_per_cu();
 
@@ -118,7 +118,7 @@ void launch_invert_diag_blocks(const T* tile, int ld, int kb, T* winv, int* info
 // potrf_coop_sync_words(kb).
 template <class T>
 void launch_potrf_coop(T* tile, int ld, int kb, T* winv, int* info, int info_base, unsigned* sync,
-                       hipStream_t stream);
+                       hipStream_t stream, bool sync_is_zero = false);
 inline size_t potrf_coop_sync_words(int kb) {
   const size_t g = (size_t) ((kb + kDiagBlock - 1) / kDiagBlock);
   return g + g * g;

@@ -591,13 +591,16 @@ static void fatal_device_config(const char* what) {
 
 template <class T>
 void launch_potrf_coop(T* tile, int ld, int kb, T* winv, int* info, int info_base, unsigned* sync,
-                       hipStream_t stream) {
+                       hipStream_t stream, bool sync_is_zero) {
   if (kb <= 0)
     return;
   const int G = (kb + kCB - 1) / kCB;
   if (G > kThreads)
     fatal_device_config("potrf_coop: more than 256 strips per tile");
-  (void) hipMemsetAsync(sync, 0, sizeof(unsigned) * ((size_t) G + (size_t) G * G), stream);
+  // (a caller that hands every launch its own slice of a buffer it zeroed once saves a fill kernel per tile on
+  // the critical path of the factorization)
+  if (!sync_is_zero)
+    (void) hipMemsetAsync(sync, 0, sizeof(unsigned) * ((size_t) G + (size_t) G * G), stream);
   hipLaunchKernelGGL((potrf_coop_kernel<T>), dim3((unsigned) G), dim3(kThreads), CoopCfg<T>::LDS_BYTES, stream, tile, ld,
                      kb, winv, info, info_base, sync, coop_spin_limit());
 }
@@ -615,9 +618,9 @@ void potrf_coop_kernels_init() {
   coop_init_one<cdouble>();
 }
 
-template void launch_potrf_coop<float>(float*, int, int, float*, int*, int, unsigned*, hipStream_t);
-template void launch_potrf_coop<double>(double*, int, int, double*, int*, int, unsigned*, hipStream_t);
-template void launch_potrf_coop<cfloat>(cfloat*, int, int, cfloat*, int*, int, unsigned*, hipStream_t);
-template void launch_potrf_coop<cdouble>(cdouble*, int, int, cdouble*, int*, int, unsigned*, hipStream_t);
+template void launch_potrf_coop<float>(float*, int, int, float*, int*, int, unsigned*, hipStream_t, bool);
+template void launch_potrf_coop<double>(double*, int, int, double*, int*, int, unsigned*, hipStream_t, bool);
+template void launch_potrf_coop<cfloat>(cfloat*, int, int, cfloat*, int*, int, unsigned*, hipStream_t, bool);
+template void launch_potrf_coop<cdouble>(cdouble*, int, int, cdouble*, int*, int, unsigned*, hipStream_t, bool);
 
 }  // namespace dlaf_mi355x

@@ -471,7 +471,8 @@ static bool aligned16(const void* ptr, long stride_elems) {
 }
 
 template <class T>
-void launch_update(const UpdateArgs<T>& a, hipStream_t stream, int role, long max_blocks, unsigned* counters) {
+void launch_update(const UpdateArgs<T>& a, hipStream_t stream, int role, long max_blocks, unsigned* counters,
+                   bool counters_are_zero) {
   using Cfg = typename UpdateCfg<T>::type;
   if (a.il1 <= a.il0 || a.jl1 <= a.jl0 || a.K <= 0 || a.nb <= 0)
     return;
@@ -530,7 +531,8 @@ void launch_update(const UpdateArgs<T>& a, hipStream_t stream, int role, long ma
     mp.counters = counters;
     mp.lockstep = update_lockstep() ? 1 : 0;
     mp.kphase_ticks = kphase_ticks<T>((int) (grid));
-    (void) hipMemsetAsync(counters, 0, 16 * sizeof(unsigned), stream);
+    if (!counters_are_zero)
+      (void) hipMemsetAsync(counters, 0, 16 * sizeof(unsigned), stream);
   }
   const bool vec = aligned16<T>(a.a, a.lda) && aligned16<T>(a.a, a.a_ts) && aligned16<T>(a.b, a.ldb) &&
                    aligned16<T>(a.b, a.b_ts) && aligned16<T>(a.b, a.b_ts2) &&
@@ -589,13 +591,13 @@ void update_kernels_init() {
   update_init_one<cdouble>();
 }
 
-template void launch_update<float>(const UpdateArgs<float>&, hipStream_t, int, long, unsigned*);
+template void launch_update<float>(const UpdateArgs<float>&, hipStream_t, int, long, unsigned*, bool);
 template int update_blocks_per_cu<float>();
-template void launch_update<double>(const UpdateArgs<double>&, hipStream_t, int, long, unsigned*);
+template void launch_update<double>(const UpdateArgs<double>&, hipStream_t, int, long, unsigned*, bool);
 template int update_blocks_per_cu<double>();
-template void launch_update<cfloat>(const UpdateArgs<cfloat>&, hipStream_t, int, long, unsigned*);
+template void launch_update<cfloat>(const UpdateArgs<cfloat>&, hipStream_t, int, long, unsigned*, bool);
 template int update_blocks_per_cu<cfloat>();
-template void launch_update<cdouble>(const UpdateArgs<cdouble>&, hipStream_t, int, long, unsigned*);
+template void launch_update<cdouble>(const UpdateArgs<cdouble>&, hipStream_t, int, long, unsigned*, bool);
 template int update_blocks_per_cu<cdouble>();
 
 }  // namespace dlaf_mi355x

@@ -222,8 +222,18 @@ void DeviceMatrix<T>::create(Grid* g, char uplo_, long n_, int nb_, int isrc, in
   }
   DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&info), sizeof(int)));
   DLAF_HIP_CHECK(hipMemset(info, 0, sizeof(int)));
-  // [8 dequeue heads + 8 pacing counters of the persistent update launches | flags of the cooperative tile POTRF]
-  DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&coop_sync), sizeof(unsigned) * (16 + potrf_coop_sync_words(nb))));
+  // Flags and counters of the launches that need them: a slice of 16 words (8 dequeue heads + 8 pacing counters)
+  // per persistent update launch, then a slice per diagonal tile for the cooperative POTRF.  The whole buffer is
+  // zeroed ONCE per factorization and every launch gets a slice of its own: no fill kernel in front of every
+  // bulk launch and every tile POTRF.  (Measured A/B on one box, N = 32768 nb = 512: 59.43 against 59.40 TFlop/s --
+  // the fill kernels were not on the critical path; kept because it removes ~110 launches per factorization.)
+  {
+    const size_t nt_ = (size_t) std::max<long>(1, (n + nb - 1) / nb);
+    coop_sync_update_slices = 6 * nt_ + 8;
+    coop_sync_potrf_words = potrf_coop_sync_words(nb);
+    coop_sync_words = 16 * coop_sync_update_slices + coop_sync_potrf_words * nt_;
+  }
+  DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&coop_sync), sizeof(unsigned) * coop_sync_words));
   DLAF_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&info_host), sizeof(int), hipHostMallocDefault));
   *info_host = 0;
 
@@ -478,12 +488,13 @@ static bool potrf_use_chain() {
 }
 
 template <class T>
-static void potrf_tile(T* t, int ld, int kb, T* winv, int* info, int info_base, unsigned* sync, hipStream_t s) {
+static void potrf_tile(T* t, int ld, int kb, T* winv, int* info, int info_base, unsigned* sync, hipStream_t s,
+                       bool sync_is_zero = false) {
   constexpr int JB = kDiagBlock;
   if (!potrf_use_chain()) {
     // one resident cooperative launch (kernels_potrf_coop.hip); DLAF_MI355X_POTRF=chain selects the
     // multi-launch form below (diagonal block kernel + TRSM kernel + update kernel per 64 columns)
-    launch_potrf_coop(t, ld, kb, winv, info, info_base, sync, s);
+    launch_potrf_coop(t, ld, kb, winv, info, info_base, sync, s, sync_is_zero);
     return;
   }
   for (int j0 = 0; j0 < kb; j0 += JB) {
@@ -663,6 +674,13 @@ void DeviceMatrix<T>::factorize_async() {
     ps.launches = 0;
   }
   DLAF_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int), s_panel));
+  DLAF_HIP_CHECK(hipMemsetAsync(coop_sync, 0, sizeof(unsigned) * coop_sync_words, s_panel));
+  size_t next_update_slice = 0;
+  // DLAF_MI355X_SYNC_POOL=0: a fill kernel per launch instead (A/B)
+  const bool sync_pool = [] {
+    const char* e = std::getenv("DLAF_MI355X_SYNC_POOL");
+    return e == nullptr || std::atoi(e) != 0;
+  }();
   DLAF_HIP_CHECK(hipEventRecord(ev_start[0], s_panel));
   DLAF_HIP_CHECK(hipStreamWaitEvent(s_main, ev_start[0], 0));
   DLAF_HIP_CHECK(hipStreamWaitEvent(s_comm, ev_start[0], 0));
@@ -755,7 +773,17 @@ void DeviceMatrix<T>::factorize_async() {
     update_work(il0, il1, j0, j1, st.kb, fl, by);
     const int pk = kind < 0 ? role : kind;
     prof_begin(pk, s);
-    launch_update(ua, s, role, reserve > 0 ? std::max<long>(8, bulk_slots - reserve) : 0, coop_sync);
+    // (persistent launches only: each takes the next pre-zeroed slice; past the end of the pool -- never with the
+    // schedules below -- the last slice is re-zeroed per launch)
+    unsigned* cnt = coop_sync;
+    bool zero = false;
+    if (reserve > 0) {
+      const size_t sl = std::min(next_update_slice, coop_sync_update_slices - 1);
+      cnt = coop_sync + 16 * sl;
+      zero = sync_pool && next_update_slice < coop_sync_update_slices - 1;
+      ++next_update_slice;
+    }
+    launch_update(ua, s, role, reserve > 0 ? std::max<long>(8, bulk_slots - reserve) : 0, cnt, zero);
     prof_end(pk, s, fl, by);
   };
 
@@ -803,7 +831,8 @@ void DeviceMatrix<T>::factorize_async() {
     const int kb = rows.tile_extent(k);
     const double cxf = TypeInfo<T>::is_complex ? 4.0 : 1.0;
     prof_begin(3, s_panel);
-    potrf_tile(tile(rows.local_of(k), cols.local_of(k)), nb, kb, winv_of(k), info, (int) (k * nb), coop_sync + 16, s_panel);
+    potrf_tile(tile(rows.local_of(k), cols.local_of(k)), nb, kb, winv_of(k), info, (int) (k * nb),
+               coop_sync + 16 * coop_sync_update_slices + coop_sync_potrf_words * (size_t) k, s_panel, sync_pool);
     prof_end(3, s_panel, cxf * (double) kb * kb * kb / 3.0, (double) kb * kb * sizeof(T));
   };
 

@@ -126,7 +126,8 @@ struct DeviceMatrix : MatrixBase {
   T* panelT[2] = {nullptr, nullptr};  // ltc tiles each (transposed panel)
   T* staging = nullptr;     // column-major staging for upload/download
   size_t staging_elems = 0;
-  unsigned* coop_sync = nullptr;  // flags / counters of the cooperative tile POTRF
+  unsigned* coop_sync = nullptr;  // flags / counters: [update slices | one slice per diagonal tile], see the constructor
+  size_t coop_sync_words = 0, coop_sync_update_slices = 0, coop_sync_potrf_words = 0;
   int* info = nullptr;      // device flag
   int* info_host = nullptr; // pinned
 
