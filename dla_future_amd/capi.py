@@ -74,6 +74,7 @@ SIGNATURES = {
     "dlaf_mi355x_matrix_copy": (_i, [_vp, _vp]),
     "dlaf_mi355x_matrix_fetch_tile": (_i, [_vp, _l, _l, _vp, _i]),
     "dlaf_mi355x_grid_on_free": (_i, [_i, _vp, _vp]),
+    "dlaf_mi355x_grid_rekey": (_i, [_i, _i]),
     "dlaf_mi355x_grid_comm_log": (_i, [_i, _i]),
     "dlaf_mi355x_grid_comm_log_read": (_l, [_i, C.POINTER(C.c_long), _l]),
     "dlaf_mi355x_cholesky_start": (_i, [_vp]),

@@ -357,6 +357,20 @@ int dlaf_mi355x_create_grid_host(int nranks, int rank, int nprow, int npcol, cha
   return register_grid(std::move(g));
 }
 
+int dlaf_mi355x_grid_rekey(int ctx, int new_ctx) noexcept {
+  auto it = g_grids.find(ctx);
+  if (it == g_grids.end())
+    return -1;
+  if (ctx == new_ctx)
+    return 0;
+  if (g_grids.find(new_ctx) != g_grids.end())
+    return -2;
+  std::unique_ptr<Grid> g = std::move(it->second);
+  g_grids.erase(it);
+  g_grids.emplace(new_ctx, std::move(g));
+  return 0;
+}
+
 int dlaf_mi355x_grid_on_free(int ctx, void (*fn)(void*), void* user) noexcept {
   auto it = g_grids.find(ctx);
   if (it == g_grids.end())

@@ -3,6 +3,7 @@
 //
 //   dlaf_create_grid(MPI_Comm, nprow, npcol, order)     include/dlaf_c/grid.h:31, src/c_api/grid.cpp:28-39
 //   grid_ordering(MPI_Comm, nprow, npcol, myprow, mypcol)  include/dlaf_c/grid.h:54, src/c_api/grid.cpp:45-68
+//   dlaf_create_grid_from_blacs(blacs_ctxt)              include/dlaf_c/grid.h:71, src/c_api/grid.cpp:73-92
 //
 // MPI is used for what the reference uses it for at this point -- the barrier and the process
 // layout -- plus the bootstrap of the device transport:
@@ -13,6 +14,8 @@
 //       (communication/kernels/internal/broadcast.h:62-70); lets several ranks share one GPU.
 #define DLAF_MI355X_WITH_MPI 1
 #include <mpi.h>
+
+#include <dlfcn.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -109,4 +112,40 @@ extern "C" char grid_ordering(MPI_Comm comm, int nprow, int npcol, int myprow, i
     std::exit(-1);
   }
   return all[1] ? 'C' : 'R';
+}
+
+// reference: src/c_api/grid.cpp:73-92 (compiled there under DLAF_WITH_SCALAPACK against src/c_api/blacs.h).  The
+// three BLACS functions are resolved in the running program: nothing here links a ScaLAPACK.
+extern "C" void dlaf_create_grid_from_blacs(int blacs_ctxt) noexcept {
+  using get_fn = void (*)(int, int, int*);
+  using handle_fn = MPI_Comm (*)(int);
+  using info_fn = void (*)(int, int*, int*, int*, int*);
+  auto blacs_get = reinterpret_cast<get_fn>(dlsym(RTLD_DEFAULT, "Cblacs_get"));
+  auto blacs2sys = reinterpret_cast<handle_fn>(dlsym(RTLD_DEFAULT, "Cblacs2sys_handle"));
+  auto blacs_info = reinterpret_cast<info_fn>(dlsym(RTLD_DEFAULT, "Cblacs_gridinfo"));
+  if (!blacs_get || !blacs2sys || !blacs_info) {
+    std::fprintf(stderr, "[dlaf_mi355x] dlaf_create_grid_from_blacs: no BLACS (Cblacs_get / Cblacs2sys_handle / "
+                         "Cblacs_gridinfo) in this program\n");
+    std::abort();
+  }
+  int probe[4];
+  if (dlaf_mi355x_grid_info(blacs_ctxt, &probe[0], &probe[1], &probe[2], &probe[3]) == 0)
+    return;  // already registered: try_emplace semantics of the reference
+  int system_ctxt = 0;
+  blacs_get(blacs_ctxt, 10, &system_ctxt);  // SGET_BLACSCONTXT == 10
+  MPI_Comm communicator = blacs2sys(system_ctxt);
+  int dims[2] = {0, 0}, coords[2] = {-1, -1};
+  blacs_info(blacs_ctxt, &dims[0], &dims[1], &coords[0], &coords[1]);
+  const char order = grid_ordering(communicator, dims[0], dims[1], coords[0], coords[1]);
+  const int ctx = dlaf_create_grid(communicator, dims[0], dims[1], order);
+  if (dlaf_mi355x_grid_rekey(ctx, blacs_ctxt) != 0) {
+    std::fprintf(stderr, "[dlaf_mi355x] dlaf_create_grid_from_blacs: context %d cannot be registered\n", blacs_ctxt);
+    std::abort();
+  }
+  auto it = g_comms.find(ctx);  // (host transport: the communicators follow the grid to its new number)
+  if (it != g_comms.end()) {
+    std::unique_ptr<MpiComms> c = std::move(it->second);
+    g_comms.erase(it);
+    g_comms.emplace(blacs_ctxt, std::move(c));
+  }
 }

@@ -15,6 +15,11 @@
 DLAF_EXTERN_C int dlaf_create_grid(MPI_Comm comm, int nprow, int npcol, char order) DLAF_NOEXCEPT;
 /* reference: grid.h:54 */
 DLAF_EXTERN_C char grid_ordering(MPI_Comm comm, int nprow, int npcol, int myprow, int mypcol) DLAF_NOEXCEPT;
+/* reference: grid.h:71 (there under DLAF_WITH_SCALAPACK) -- the grid of an existing BLACS context, registered
+ * under that context number, so that dlaf_p?potrf finds it through desca[1] like a ScaLAPACK routine would.  The
+ * BLACS entry points (Cblacs_get, Cblacs2sys_handle, Cblacs_gridinfo) are taken from the calling program at run
+ * time: a caller that has a BLACS context has a BLACS library loaded. */
+DLAF_EXTERN_C void dlaf_create_grid_from_blacs(int blacs_ctxt) DLAF_NOEXCEPT;
 #endif
 
 /* reference: grid.h:39 */

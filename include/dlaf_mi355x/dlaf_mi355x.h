@@ -47,6 +47,10 @@ DLAF_EXTERN_C int dlaf_mi355x_grid_host_bcast(int context, int axis, int root, v
 /* fn(user) is called once when the grid is freed (dlaf_free_grid / dlaf_finalize): the creator of a host
  * grid releases there what its callbacks use (the MPI shim frees its communicators).  -1: unknown context. */
 DLAF_EXTERN_C int dlaf_mi355x_grid_on_free(int context, void (*fn)(void*), void* user) DLAF_NOEXCEPT;
+/* Moves a registered grid to the context number `new_ctx` (0: done, -1: unknown ctx, -2: new_ctx is taken).  The
+ * MPI shim uses it for dlaf_create_grid_from_blacs, whose grids are looked up by the caller's BLACS context
+ * (reference: src/c_api/grid.cpp:73-92 registers the grid under blacs_ctxt). */
+DLAF_EXTERN_C int dlaf_mi355x_grid_rekey(int ctx, int new_ctx) DLAF_NOEXCEPT;
 
 /* Communication log of a grid (test instrument): while enabled, every broadcast / barrier / all-reduce the
  * library issues on this grid and a marker per factorization step are appended to a per-process list of

@@ -37,6 +37,34 @@ def build(name):
     return out
 
 
+BLACS_LIBS = ["-lmkl_blacs_intelmpi_lp64", "-lmkl_intel_lp64", "-lmkl_sequential", "-lmkl_core", "-ldl", "-lpthread"]
+
+
+def build_blacs():
+    """tests/c_api/test_blacs_grid.c against the image's MKL BLACS (MPICH ABI) -- the BLACS a ScaLAPACK caller has."""
+    build("test_grid_mpi")  # (the shim)
+    libdir = os.path.join(os.path.dirname(os.path.dirname(MPICC)), "lib")
+    if not os.path.exists(os.path.join(libdir, "libmkl_blacs_intelmpi_lp64.so")):
+        pytest.skip("no BLACS library in the image")
+    out = os.path.join(ROOT, "tests", "c_api", "test_blacs_grid")
+    src = out + ".c"
+    # the MKL libraries are reached through links in the (untracked) lib/mpi directory, like libmpi itself: the
+    # MPI tree's lib directory must stay out of the link and run paths (it carries an old libstdc++)
+    for name in ("libmkl_blacs_intelmpi_lp64.so", "libmkl_intel_lp64.so", "libmkl_sequential.so", "libmkl_core.so",
+                 "libmkl_intel_lp64.so.1", "libmkl_sequential.so.1", "libmkl_core.so.1", "libmkl_blacs_intelmpi_lp64.so.1"):
+        link = os.path.join(LIB, "mpi", name)
+        if os.path.exists(os.path.join(libdir, name)) and not os.path.lexists(link):
+            os.symlink(os.path.join(libdir, name), link)
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        inc = os.path.join(os.path.dirname(os.path.dirname(MPICC)), "include")
+        subprocess.run(["gcc", "-std=c11", "-O1", "-Wall", src, "-I", os.path.join(ROOT, "include"), "-I", inc,
+                        "-DDLAF_MI355X_WITH_MPI", "-L", LIB, "-L", os.path.join(LIB, "mpi"),
+                        "-ldlaf_mi355x_mpi", "-ldlaf_mi355x"] + BLACS_LIBS +
+                       ["-lmpi", "-lm", f"-Wl,-rpath-link,{LIB}/mpi", f"-Wl,-rpath,{LIB}", f"-Wl,-rpath,{LIB}/mpi",
+                        "-Wl,-rpath,/opt/rocm/lib", "-o", out], check=True)
+    return out
+
+
 def run(exe, nprow, npcol, order, timeout, env_extra=None):
     env = dict(os.environ, DLAF_MI355X_MPI_TRANSPORT="host", DLAF_MI355X_DEVICE="0", OMP_NUM_THREADS="1")
     env.pop("LOCAL_RANK", None)
@@ -79,3 +107,24 @@ def test_mpi_shim_exports_the_mpi_guarded_declarations():
                          capture_output=True, text=True, check=True).stdout
     exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
     assert names <= exported, names - exported
+
+
+@pytest.mark.parametrize("nprow,npcol,order", [(1, 1, "R"), (2, 2, "R"), (3, 2, "C"), (1, 2, "C")])
+def test_grid_from_blacs_context_cpu(nprow, npcol, order):
+    """dlaf_create_grid_from_blacs: the grid of an existing BLACS context, found again under that context."""
+    exe = build_blacs()
+    r = run(exe, nprow, npcol, order, 120)
+    assert r.returncode == 0 and "BLACS_GRID_TEST OK" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nprow,npcol,order", [(1, 1, "R"), (2, 2, "C")])
+def test_pdpotrf_on_a_blacs_context(nprow, npcol, order):
+    """The ScaLAPACK application's call sequence: BLACS grid, dlaf_create_grid_from_blacs, dlaf_pdpotrf with the
+    BLACS context in the descriptor."""
+    exe = build_blacs()
+    env = dict(os.environ, DLAF_MI355X_MPI_TRANSPORT="host", DLAF_MI355X_DEVICE="0", OMP_NUM_THREADS="1")
+    env.pop("LOCAL_RANK", None)
+    r = subprocess.run([MPIEXEC, "-n", str(nprow * npcol), exe, str(nprow), str(npcol), order, "factorize"], cwd=ROOT,
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "BLACS_GRID_TEST OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
