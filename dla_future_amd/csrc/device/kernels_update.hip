@@ -34,6 +34,10 @@ struct UpdateCfg<double> {
   // L2 -> LDS bytes per flop than two independent 128 x 128 blocks
   using type = BlockCfg<double, 256, 128, 64, 64, 16, true, DLAF_UPD_BIG, 512>;
   static constexpr int min_waves = 2;
+#elif defined(DLAF_UPD_BK) && defined(DLAF_UPD_ST)
+  // tuning aid (tools/run_ab_ring.sh): slab depth / ring depth of the direct-to-LDS pipeline
+  using type = BlockCfg<double, 128, 128, 64, 64, DLAF_UPD_BK, true, DLAF_UPD_ST>;
+  static constexpr int min_waves = 2;
 #else
   using type = BlockCfg<double, 128, 128, 64, 64, 16, true, 2>;
   static constexpr int min_waves = 2;

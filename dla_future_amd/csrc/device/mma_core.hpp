@@ -51,7 +51,7 @@ struct BlockCfg {
   static constexpr int A_ELEMS = (CX ? 2 : 1) * A_PLANE, B_ELEMS = (CX ? 2 : 1) * B_PLANE;
   static constexpr int BUF_ELEMS = A_ELEMS + B_ELEMS;
   static constexpr int STAGES = STAGES_;
-  static_assert(STAGES >= 2 && STAGES <= 4, "2..4 LDS stages");
+  static_assert(STAGES >= 2 && STAGES <= 6, "2..6 LDS stages");
   static constexpr int LDS_BYTES = STAGES * BUF_ELEMS * (int) sizeof(R);
 };
 
