@@ -175,6 +175,20 @@ __device__ __forceinline__ void update_block(const UpdateArgs<T>& p, const Updat
 #endif
   T* C = p.c + (long) il * p.c_tsr + (long) jl * p.c_tsc + m0 + (long) n0 * p.ldc;
 
+  // The operand bases are the same for every lane of the workgroup; say so (they come out of the work-item
+  // decoding above in vector registers): the in-loop loads then take (scalar base) + (32-bit lane offset).
+  auto uniform = [](const T* q) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(q);
+    const unsigned lo = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) v);
+    const unsigned hi = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (v >> 32));
+    return reinterpret_cast<const T*>(((unsigned long long) hi << 32) | lo);
+  };
+#if DLAF_GLDS_SCALAR_ADDR
+  A = uniform(A);
+  B = uniform(B);
+  A2 = uniform(A2);
+  B2 = uniform(B2);
+#endif
   const bool full = (mrows == Cfg::BM) && (ncols == Cfg::BN) && (p.K % Cfg::BK == 0) && (p.K1 % Cfg::BK == 0);
   Acc<Cfg> acc;
 #ifndef DLAF_UPD_PRELOAD
@@ -410,8 +424,16 @@ __global__ __launch_bounds__(UpdateCfg<T>::type::THREADS, UpdateCfg<T>::min_wave
       next_s0 = (mp.kphase_ticks != 0 && nslab > 1) ? (int) ((wall_clock64() / mp.kphase_ticks) % (unsigned) nslab) : 0;
     }
     __syncthreads();
+    // (wave-uniform: everything derived from the work item -- operand and C addresses, segment selection, the
+    // LDS ring -- then lives in scalar registers; left as a per-lane LDS value, the address of every in-loop load
+    // costs a 64-bit multiply-add and a select per lane in the middle of the MFMA stream)
+#if DLAF_GLDS_SCALAR_ADDR
+    const long i = (long) (unsigned) __builtin_amdgcn_readfirstlane((int) next_item);
+    const int s0 = __builtin_amdgcn_readfirstlane(next_s0);
+#else
     const long i = next_item;
     const int s0 = next_s0;
+#endif
     __syncthreads();
     if (i >= per_q)
       break;

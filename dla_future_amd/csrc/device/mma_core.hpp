@@ -236,12 +236,25 @@ __device__ __forceinline__ void stage_glds(const T* __restrict__ A, long lda, co
 
 // The IDX-th of the LPS instructions stage_glds issues for this wave (real types), alone: lets the pipelined
 // loop spread them over the MFMA stream.
+#ifndef DLAF_GLDS_SCALAR_ADDR
+#define DLAF_GLDS_SCALAR_ADDR 1  // 0: the per-lane address arithmetic of rounds 1-2 (A/B, tools/run_ab_saddr.sh)
+#endif
 template <class Cfg, class T, int IDX>
 __device__ __forceinline__ void stage_glds_one(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb,
                                                int k0, typename Cfg::R* __restrict__ buf, int wave, int lane) {
   static_assert(!Cfg::CXI, "real types");
   constexpr int NA = Cfg::PIECES_A / Cfg::NWAVES, NB = Cfg::PIECES_B / Cfg::NWAVES;
   constexpr int PER = 16 / (int) sizeof(T), EPP = Cfg::EPP;
+  // address = (wave-uniform base: scalar registers) + (a per-lane byte offset that does not depend on the slab):
+  // a piece is EPP consecutive elements of the image [k][ROWS] starting at element e0 (uniform); lane l moves the
+  // PER elements at e0 + l PER, i.e. row (e0 + l PER) % ROWS of column (e0 + l PER) / ROWS.  With ROWS | EPP or
+  // EPP | ROWS the lane part is (l PER) % ROWS + ((l PER) / ROWS) ld and the uniform part (e0 % ROWS) + (k0 + e0 /
+  // ROWS) ld.  Written per lane -- "(e % ROWS) + (k0 + e / ROWS) * ld" -- every load costs a 64-bit multiply-add
+  // per lane in the middle of the MFMA stream.
+  auto at = [](const T* base, unsigned byte_off) {
+    return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+  };
+#if !DLAF_GLDS_SCALAR_ADDR
   if constexpr (IDX < NA) {
     const int e0 = (wave * NA + IDX) * EPP;
     const int e = e0 + lane * PER;
@@ -254,6 +267,24 @@ __device__ __forceinline__ void stage_glds_one(const T* __restrict__ A, long lda
     const int e = e0 + lane * PER;
     const T* gb = B + (e % Cfg::BN) + (long) (k0 + e / Cfg::BN) * ldb;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) gb,
+                                     (__attribute__((address_space(3))) void*) (buf + Cfg::A_ELEMS + e0), 16, 0, 0);
+  }
+  return;
+#endif
+  if constexpr (IDX < NA) {
+    static_assert(EPP % Cfg::BM == 0 || Cfg::BM % EPP == 0, "pieces and columns nest");
+    const int e0 = (wave * NA + IDX) * EPP;
+    const unsigned loff = (unsigned) sizeof(T) * (unsigned) ((lane * PER) % Cfg::BM + ((lane * PER) / Cfg::BM) * (int) lda);
+    const T* ga = A + (e0 % Cfg::BM) + (long) (k0 + e0 / Cfg::BM) * lda;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) at(ga, loff),
+                                     (__attribute__((address_space(3))) void*) (buf + e0), 16, 0, 0);
+  }
+  else if constexpr (IDX < NA + NB) {
+    static_assert(EPP % Cfg::BN == 0 || Cfg::BN % EPP == 0, "pieces and columns nest");
+    const int e0 = (wave * NB + (IDX - NA)) * EPP;
+    const unsigned loff = (unsigned) sizeof(T) * (unsigned) ((lane * PER) % Cfg::BN + ((lane * PER) / Cfg::BN) * (int) ldb);
+    const T* gb = B + (e0 % Cfg::BN) + (long) (k0 + e0 / Cfg::BN) * ldb;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) at(gb, loff),
                                      (__attribute__((address_space(3))) void*) (buf + Cfg::A_ELEMS + e0), 16, 0, 0);
   }
 }
@@ -277,7 +308,11 @@ __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda,
                                               const T* __restrict__ B2 = nullptr, int s0 = 0) {
   using R = typename Cfg::R;
   const int lane = threadIdx.x & 63;
+#if DLAF_GLDS_SCALAR_ADDR
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: scalar address math
+#else
   const int wave = threadIdx.x >> 6;
+#endif
   const int wm = wave % Cfg::WAVES_M, wn = wave / Cfg::WAVES_M;
   const int nk = (K + Cfg::BK - 1) / Cfg::BK;
   if (nk == 0)
@@ -370,7 +405,9 @@ __device__ __forceinline__ void gemm_nt_block(const T* __restrict__ A, long lda,
 #ifdef DLAF_DBG_STAMPS
       const unsigned long long t3 = __builtin_amdgcn_s_memtime();
 #endif
+#ifndef DLAF_DBG_NO_SLAB_BARRIER  // tuning aid (timing only, the results are garbage): what the slab barrier costs
       __builtin_amdgcn_s_barrier();
+#endif
 #ifdef DLAF_DBG_STAMPS
       const unsigned long long t4 = __builtin_amdgcn_s_memtime();
       st_mma += t2 - t0;
