@@ -271,7 +271,7 @@ __device__ __forceinline__ void update_block(const UpdateArgs<T>& p, const Updat
     const bool wide = !masked && VEC && ((p.ldc * (long) sizeof(T)) % 16 == 0) &&
                       (reinterpret_cast<uintptr_t>(C) % 16 == 0);
 #ifndef DLAF_EPI_COLS
-#define DLAF_EPI_COLS 1
+#define DLAF_EPI_COLS 4  // A/B on one MI355X (tools/run_ab_epi.sh): 1 -> 4 columns per round trip +0.7 ... 1.2 % on the bulk launches
 #endif
     if (wide) {
       // DLAF_EPI_COLS accumulator columns (a column = one (j, v) pair, TM/2 16-byte accesses per lane) are

@@ -150,7 +150,7 @@ __device__ __forceinline__ void mma_slab(const typename Cfg::R* __restrict__ As,
             // (ar + i ai)(br - i bi) = (ar br + ai bi) + i (ai br - ar bi)
             acc.re[i][j] = Mma<R>::mma(b_im[j], a_im[i], acc.re[i][j]);
             acc.im[i][j] = Mma<R>::mma(b_re[j], a_im[i], acc.im[i][j]);
-            acc.im[i][j] = Mma<R>::mma(b_im[j], -a_re[i], acc.im[i][j]);
+            acc.im[i][j] = Mma<R>::mma_neg(b_im[j], a_re[i], acc.im[i][j]);  // (f64: the MFMA's own negate bit)
           }
         }
         else {
