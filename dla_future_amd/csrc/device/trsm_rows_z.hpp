@@ -158,14 +158,13 @@ __global__ __launch_bounds__(kThreads, 1) void trsm_rows_z_kernel(TrsmArgs<cdoub
       for (int k4 = 0; k4 < 2; ++k4) {
         const int kk = 4 * k4 + g;
         const d2 xf = *reinterpret_cast<const d2*>(&buf[kk * C::ROWS + mrow]);
-        const double nxr = -xf[0];
 #pragma unroll
         for (int t = 0; t < C::NT; ++t) {
           const d2 lf = *reinterpret_cast<const d2*>(&buf[C::A_ELEMS + kk * NW + 16 * t + c]);
           Sre[t] = Mma<double>::mma(lf[0], xf[0], Sre[t]);
           Sre[t] = Mma<double>::mma(lf[1], xf[1], Sre[t]);
           Sim[t] = Mma<double>::mma(lf[0], xf[1], Sim[t]);
-          Sim[t] = Mma<double>::mma(lf[1], nxr, Sim[t]);
+          Sim[t] = Mma<double>::mma_neg(lf[1], xf[0], Sim[t]);
         }
       }
       ring_step_end(i);
@@ -197,7 +196,7 @@ __global__ __launch_bounds__(kThreads, 1) void trsm_rows_z_kernel(TrsmArgs<cdoub
             Xre[j2] = Mma<double>::mma(wf[0], Bre[ct][v], Xre[j2]);
             Xre[j2] = Mma<double>::mma(wf[1], Bim[ct][v], Xre[j2]);
             Xim[j2] = Mma<double>::mma(wf[0], Bim[ct][v], Xim[j2]);
-            Xim[j2] = Mma<double>::mma(-wf[1], Bre[ct][v], Xim[j2]);
+            Xim[j2] = Mma<double>::mma_neg(wf[1], Bre[ct][v], Xim[j2]);
           }
 #pragma unroll
       for (int t4 = 0; t4 < 4; ++t4)
@@ -224,7 +223,6 @@ __global__ __launch_bounds__(kThreads, 1) void trsm_rows_z_kernel(TrsmArgs<cdoub
         for (int b = 0; b < 2; ++b) {
           // stage columns 8 uu + 4 b + g of the sub-block <-> register 2 (uu & 1) + b of tile uu >> 1
           const double xr = Xre[uu >> 1][2 * (uu & 1) + b], xi = Xim[uu >> 1][2 * (uu & 1) + b];
-          const double nxr = -xr;
           const int kk = 4 * b + g;
 #pragma unroll
           for (int t = tmin; t < C::NT; ++t) {
@@ -232,7 +230,7 @@ __global__ __launch_bounds__(kThreads, 1) void trsm_rows_z_kernel(TrsmArgs<cdoub
             Sre[t] = Mma<double>::mma(lf[0], xr, Sre[t]);
             Sre[t] = Mma<double>::mma(lf[1], xi, Sre[t]);
             Sim[t] = Mma<double>::mma(lf[0], xi, Sim[t]);
-            Sim[t] = Mma<double>::mma(lf[1], nxr, Sim[t]);
+            Sim[t] = Mma<double>::mma_neg(lf[1], xr, Sim[t]);
           }
         }
         ring_step_end(i);
