@@ -11,6 +11,7 @@ Python doorway onto that ABI, mirroring the reference's operator surface for the
     dlaf::cholesky_factorization(uplo, Matrix&)        include/dlaf/factorization/cholesky.h:39-79
     dlaf::triangular_solver(side, uplo, op, diag, ...)  include/dlaf/solver/triangular.h:41-177 (next row, SURVEY 8(f)2)
     generalized_to_standard(grid, uplo, A, B)          include/dlaf/eigensolver/gen_to_std.h:50,:101
+    reduction_to_band / bt_reduction_to_band           include/dlaf/eigensolver/reduction_to_band.h:40-122, bt_reduction_to_band.h
 
 There is no CPU fallback: importing works anywhere, every compute call needs the HIP library
 and a GPU and fails loudly otherwise.
@@ -20,8 +21,11 @@ from .cholesky import (DeviceMatrix, GeneralDeviceMatrix, Grid, cholesky_factori
                        initialize, make_descriptor, pxhegst, pxpotrf, pxpotrs, pxtrsm, set_random_hermitian_positive_definite, tile_gemm, tile_herk, tile_potrf,
                        tile_trsm, triangular_solver, triangular_solver_device, potrs_device, solver_profile)
 from . import distribution  # noqa: F401
+from .eigensolver import (bt_reduction_to_band, bt_reduction_to_band_device, get_band_size, red2band_profile,  # noqa: F401
+                          reduction_to_band, reduction_to_band_device)
 
-__all__ = ["DLAFDescriptor", "DeviceMatrix", "GeneralDeviceMatrix", "Grid", "LibraryNotBuilt", "cholesky_factorization", "distribution",
+__all__ = ["bt_reduction_to_band", "bt_reduction_to_band_device", "get_band_size", "red2band_profile",
+           "reduction_to_band", "reduction_to_band_device", "DLAFDescriptor", "DeviceMatrix", "GeneralDeviceMatrix", "Grid", "LibraryNotBuilt", "cholesky_factorization", "distribution",
            "finalize", "generalized_to_standard", "initialize", "lib", "lib_path", "make_descriptor", "pxhegst", "pxpotrf", "pxpotrs", "pxtrsm",
            "set_random_hermitian_positive_definite", "solver_profile", "tile_gemm", "tile_herk", "tile_potrf", "tile_trsm",
            "triangular_solver", "triangular_solver_device", "potrs_device", "type_char", "version"]

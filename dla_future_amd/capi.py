@@ -112,6 +112,18 @@ SIGNATURES = {
     "dlaf_mi355x_pchegst": (None, [_i, _ch, _i, _vp, _i, _i, _IP, _vp, _i, _i, _IP, _vp, _IP]),
     "dlaf_mi355x_pzhegst": (None, [_i, _ch, _i, _vp, _i, _i, _IP, _vp, _i, _i, _IP, _vp, _IP]),
     "dlaf_mi355x_generalized_to_standard_device": (_i, [_vp, _vp]),
+    "dlaf_mi355x_reduction_to_band_s": (_i, [_i, _vp, DLAFDescriptor, _i, _vp]),
+    "dlaf_mi355x_reduction_to_band_d": (_i, [_i, _vp, DLAFDescriptor, _i, _vp]),
+    "dlaf_mi355x_reduction_to_band_c": (_i, [_i, _vp, DLAFDescriptor, _i, _vp]),
+    "dlaf_mi355x_reduction_to_band_z": (_i, [_i, _vp, DLAFDescriptor, _i, _vp]),
+    "dlaf_mi355x_reduction_to_band_device": (_i, [_vp, _i, _vp]),
+    "dlaf_mi355x_bt_reduction_to_band_s": (_i, [_i, _i, _vp, DLAFDescriptor, _vp, DLAFDescriptor, _vp]),
+    "dlaf_mi355x_bt_reduction_to_band_d": (_i, [_i, _i, _vp, DLAFDescriptor, _vp, DLAFDescriptor, _vp]),
+    "dlaf_mi355x_bt_reduction_to_band_c": (_i, [_i, _i, _vp, DLAFDescriptor, _vp, DLAFDescriptor, _vp]),
+    "dlaf_mi355x_bt_reduction_to_band_z": (_i, [_i, _i, _vp, DLAFDescriptor, _vp, DLAFDescriptor, _vp]),
+    "dlaf_mi355x_bt_reduction_to_band_device": (_i, [_i, _vp, _vp, _vp]),
+    "dlaf_mi355x_get_band_size": (_i, [_i]),
+    "dlaf_mi355x_red2band_profile": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dlaf_mi355x_set_random_hpd": (_i, [_i, _ch, _vp, DLAFDescriptor, _i]),
     "dlaf_mi355x_tile_potrf": (_i, [_ch, _ch, _i, _vp, _i]),
     "dlaf_mi355x_tile_trsm": (_i, [_ch, _ch, _i, _i, _vp, _i, _vp, _i]),

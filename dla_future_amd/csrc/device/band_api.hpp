@@ -1,0 +1,117 @@
+// band_api.hpp -- host-callable launchers of the gfx950 kernels of the eigensolver stages built on the
+// Cholesky path's MFMA core: reduction of a Hermitian matrix to band form and its back-transformation
+// (SURVEY.md section 8(f) item 4).  Everything enqueues on the given stream and returns.
+//
+// Reference: include/dlaf/eigensolver/reduction_to_band/impl.h (panel reflectors :297-361 -- computed on the
+// CPU even by the reference's GPU backend, :881-961 -- hemm :465-517, W2 / X update :448-462, :520-542),
+// include/dlaf/factorization/qr/t_factor_impl.h, include/dlaf/eigensolver/bt_reduction_to_band/impl.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+
+namespace dlaf_mi355x {
+
+// ------------------------------------------------------------------------------------------
+// General product on column-major operands:  C = alpha * opA(A) * opB(B) + beta * C
+//   opa 'N': A is M x K;  'C': A is K x M, used conjugate-transposed
+//   opb 'N': B is K x N;  'C': B is N x K, used conjugate-transposed
+// ksplit > 1: K is cut into ksplit chunks, every chunk's block product goes to `partial`
+// (gemm_partial_elems elements) and a second kernel sums them in a fixed order -- the form the tall-skinny
+// products with a small result (V^H V, W^H X: K = the matrix size) take, since one workgroup per output
+// block would leave the GPU idle.
+template <class T>
+struct GemmArgs {
+  int M = 0, N = 0, K = 0;
+  const T* a = nullptr;
+  long lda = 0;
+  char opa = 'N';
+  const T* b = nullptr;
+  long ldb = 0;
+  char opb = 'N';
+  T* c = nullptr;
+  long ldc = 0;
+  T alpha{}, beta{};
+  int ksplit = 1;
+  T* partial = nullptr;
+};
+template <class T>
+void launch_gemm(const GemmArgs<T>& args, hipStream_t stream);
+template <class T>
+size_t gemm_partial_elems(int M, int N, int ksplit);
+// a ksplit that fills the GPU for an M x N result with inner dimension K (1 when the output blocks alone do)
+template <class T>
+int gemm_pick_ksplit(int M, int N, long K);
+
+// ------------------------------------------------------------------------------------------
+// Products of a tile-layout matrix with a tall panel (tile (il, jl) at tiles + (il + jl * ltr) * nb^2, ld nb;
+// global tile indices gi = il * pr + ri, gj = jl * pc + ci):
+//   kind S ("straight"): out rows of local tile row il  +=  A(il, jl)   * W[rows of global tile gj]
+//   kind T ("adjoint"):  out rows of local tile col jl  +=  A(il, jl)^H * W[rows of global tile gi]
+// herm != 0 (xHEMM with a lower-stored Hermitian matrix, reduction_to_band/impl.h:465-517): kind S takes the
+// tiles gi >= gj (the diagonal tile through its Hermitian image), kind T the tiles gi > gj.  herm == 0: every
+// tile of the local range (bt_reduction_to_band's W2 = W^H C runs as kind T on the tiles of C).
+// The sources of an output tile are dealt out to `layers_*` layers (source index mod layers), one workgroup per
+// (output block, layer); every layer is a column-major panel part_*[layer]: (out tiles * nb) x ncols.
+// W: row of global element g at w[(g - e0) + c * ldw].
+template <class T>
+struct TilePanelArgs {
+  const T* tiles = nullptr;
+  long ltr = 0;
+  int nb = 1;
+  int il0 = 0, il1 = 0, jl0 = 0, jl1 = 0;
+  int pr = 1, ri = 0, pc = 1, ci = 0;
+  int nt_r = 0, last_rows = 0;  // row axis: global tiles, extent of the last one
+  int nt_c = 0, last_cols = 0;  // column axis
+  int herm = 0;
+  const T* w = nullptr;
+  long ldw = 0;
+  long e0 = 0;
+  int ncols = 0;
+  int kinds = 3;  // bit 0: S, bit 1: T
+  int layers_s = 1, layers_t = 1;
+  T* part_s = nullptr;  // layers_s panels of (il1 - il0) * nb rows
+  T* part_t = nullptr;  // layers_t panels of (jl1 - jl0) * nb rows
+};
+template <class T>
+void launch_tile_panel(const TilePanelArgs<T>& args, hipStream_t stream);
+// Hermitian case: x[(g - e0) + c * ldx] for the global rows g of the tiles I0 .. nt-1 = the layer sums of the
+// kinds whose output tile is local (zero otherwise; rows g < r0 are set to zero)
+template <class T>
+void launch_hemm_reduce(const TilePanelArgs<T>& args, long r0, T* x, long ldx, hipStream_t stream);
+// kind T alone (herm == 0): out[(jl - jl0) * nb + r + c * ldo] = sum over the layers
+template <class T>
+void launch_layers_reduce(const T* part, int layers, long rows, int ncols, T* out, long ldo, hipStream_t stream);
+// layers for `out_tiles` output tiles of `sub` row blocks each (enough work items to fill the GPU, at most `max_src`)
+int tile_panel_pick_layers(long out_tiles, int nb, int ncols, long max_src, size_t elem_size);
+
+// ------------------------------------------------------------------------------------------
+// Panel of Householder reflectors (xGEQR2 of an m x b panel, reflectors of size 1 skipped; the reference's
+// computePanelReflectors, impl.h:297-361): ONE cooperative launch.  The panel is held TRANSPOSED, qt[c + r * b]
+// = element (r, c): a thread owns a column, a workgroup a range of rows; per reflector one grid-wide
+// exchange of partial sums (norm and P^H x in the same reduction).  taus[0 .. nr).
+// scratch: panel_qr_scratch_bytes(b) of device memory (partials + counters, zeroed by the launcher).
+template <class T>
+void launch_panel_qr(T* qt, long m, int b, int nr, T* taus, void* scratch, int* info, hipStream_t stream);
+size_t panel_qr_scratch_bytes(int b, size_t elem_size);
+
+// panel column block [c0, c0 + b) of tile column jl (tile-local columns cc .. cc + b) <-> transposed panel:
+// qt[c + (g - e0) * b] for the global rows g >= r0 of the local tiles il >= il0 (to_panel) or back (!to_panel)
+template <class T>
+void launch_panel_move(T* tiles, long ltr, int nb, int il0, int il1, int jl, int pr, int ri, int nt, int last_rows,
+                       int cc, int b, T* qt, long e0, long r0, bool to_panel, hipStream_t stream);
+// v[(g - e0) + j * ldv], g in [e0, n): well-formed reflectors (impl.h:364-422): 0 above the diagonal element
+// g == r0 + j, 1 on it, qt below; columns j >= nr and rows g < r0 are zero
+template <class T>
+void launch_make_v(const T* qt, int b, int nr, long e0, long r0, long n, T* v, long ldv, hipStream_t stream);
+// T factor of a block of k reflectors from S = V^H V (k x k, lds) and taus (t_factor_impl.h:60-131); t: k x k, ldt,
+// upper triangular, the strict lower part set to zero
+template <class T>
+void launch_tfactor(const T* s, long lds_, const T* taus, int k, T* t, long ldt, hipStream_t stream);
+// zero rows [0, nrows) x ncols of a column-major array
+template <class T>
+void launch_zero_rows(T* x, long ldx, long nrows, int ncols, hipStream_t stream);
+
+void band_kernels_init();
+
+}  // namespace dlaf_mi355x

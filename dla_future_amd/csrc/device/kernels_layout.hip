@@ -343,12 +343,14 @@ void update_kernels_init();
 void trsm_kernels_init();
 void potrf_kernels_init();
 void potrf_coop_kernels_init();
+void band_kernels_init();
 
 void device_kernels_init() {
   update_kernels_init();
   trsm_kernels_init();
   potrf_kernels_init();
   potrf_coop_kernels_init();
+  band_kernels_init();
 }
 
 #define INST(T)                                                                \

@@ -15,7 +15,9 @@
 #include <dlaf_c/init.h>
 #include <dlaf_mi355x/dlaf_mi355x.h>
 
+#include "red2band.hpp"
 #include "runtime.hpp"
+#include "tile_matrix.hpp"
 
 using namespace dlaf_mi355x;
 
@@ -231,6 +233,40 @@ void pxhegst(int ibtype, char uplo, int n, HT* a, int ia, int ja, const int desc
     *scale = RT(1);
   if (info)
     *info = r;
+}
+
+// dlaf::eigensolver::internal::reduction_to_band (include/dlaf/eigensolver/reduction_to_band.h:101-122) through the
+// reference's descriptor conventions
+template <class HT>
+int red2band_c(int ctx, HT* a, const DLAF_descriptor& da, int band, HT* taus) {
+  using DT = typename DevType<HT>::type;
+  check_cholesky_desc(da);  // square matrix, square block, no offsets: reduction_to_band.h:103-106
+  Grid& g = grid_from_context(ctx);
+  if (da.isrc < 0 || da.isrc >= g.nprow || da.jsrc < 0 || da.jsrc >= g.npcol)
+    fatal("[dlaf_mi355x] source rank (%d,%d) outside the %d x %d grid\n", da.isrc, da.jsrc, g.nprow, g.npcol);
+  if (band < 2 || da.nb % band != 0)
+    fatal("[dlaf_mi355x] reduction_to_band: band_size %d must be >= 2 and divide the block size %d "
+          "(reduction_to_band.h:108-109)\n", band, da.nb);
+  return reduction_to_band_host<DT>(&g, reinterpret_cast<DT*>(a), da.ld, da.m, da.nb, da.isrc, da.jsrc, band,
+                                    reinterpret_cast<DT*>(taus));
+}
+
+template <class HT>
+int bt_red2band_c(int ctx, int band, HT* c, const DLAF_descriptor& dc, const HT* v, const DLAF_descriptor& dv,
+                  const HT* taus) {
+  using DT = typename DevType<HT>::type;
+  check_cholesky_desc(dv);
+  Grid& g = grid_from_context(ctx);
+  if (dc.i != 0 || dc.j != 0 || dc.mb != dc.nb || dc.nb != dv.nb || dc.m != dv.m || dc.isrc != dv.isrc)
+    fatal("[dlaf_mi355x] bt_reduction_to_band: C (%d x %d, block %d x %d, row source %d) must have V's block size %d, "
+          "row count %d and row source %d, and no offsets\n", dc.m, dc.n, dc.mb, dc.nb, dc.isrc, dv.nb, dv.m, dv.isrc);
+  if (dc.jsrc < 0 || dc.jsrc >= g.npcol || dv.isrc < 0 || dv.isrc >= g.nprow || dv.jsrc < 0 || dv.jsrc >= g.npcol)
+    fatal("[dlaf_mi355x] source rank outside the %d x %d grid\n", g.nprow, g.npcol);
+  if (band < 2 || dv.nb % band != 0)
+    fatal("[dlaf_mi355x] bt_reduction_to_band: band_size %d must be >= 2 and divide the block size %d\n", band, dv.nb);
+  return bt_reduction_to_band_host<DT>(&g, band, reinterpret_cast<DT*>(c), dc.ld, dc.n, dc.jsrc,
+                                       reinterpret_cast<const DT*>(v), dv.ld, dv.m, dv.nb, dv.isrc, dv.jsrc,
+                                       reinterpret_cast<const DT*>(taus));
 }
 
 struct MatrixHandle {
@@ -495,6 +531,29 @@ DLAF_MI355X_HEGST_ENTRY(c, std::complex<float>, dlaf_complex_c, float)
 DLAF_MI355X_HEGST_ENTRY(z, std::complex<double>, dlaf_complex_z, double)
 #undef DLAF_MI355X_HEGST_ENTRY
 
+#define DLAF_MI355X_R2B_ENTRY(S, HT, CT)                                                                          \
+  int dlaf_mi355x_reduction_to_band_##S(int ctx, CT* a, DLAF_descriptor desca, int band, CT* taus) noexcept {     \
+    return red2band_c<HT>(ctx, reinterpret_cast<HT*>(a), desca, band, reinterpret_cast<HT*>(taus));               \
+  }                                                                                                              \
+  int dlaf_mi355x_bt_reduction_to_band_##S(int ctx, int band, CT* c, DLAF_descriptor descc, const CT* v,          \
+                                           DLAF_descriptor descv, const CT* taus) noexcept {                     \
+    return bt_red2band_c<HT>(ctx, band, reinterpret_cast<HT*>(c), descc, reinterpret_cast<const HT*>(v), descv,   \
+                             reinterpret_cast<const HT*>(taus));                                                 \
+  }
+DLAF_MI355X_R2B_ENTRY(s, float, float)
+DLAF_MI355X_R2B_ENTRY(d, double, double)
+DLAF_MI355X_R2B_ENTRY(c, std::complex<float>, dlaf_complex_c)
+DLAF_MI355X_R2B_ENTRY(z, std::complex<double>, dlaf_complex_z)
+#undef DLAF_MI355X_R2B_ENTRY
+
+int dlaf_mi355x_get_band_size(int nb) noexcept {
+  return get_band_size(nb);
+}
+int dlaf_mi355x_red2band_profile(double* ms, double* flops) noexcept {
+  red2band_last_profile(ms, flops);
+  return 0;
+}
+
 // ---- device-resident operands for the solver ----------------------------------------------------------------
 struct dlaf_mi355x_gmatrix_s {
   std::unique_ptr<MatrixBase> m;
@@ -643,6 +702,17 @@ int dlaf_mi355x_generalized_to_standard_device(dlaf_mi355x_matrix_t a, dlaf_mi35
   if (!a || !l || a->type != l->type)
     return -1;
   WITH_MATRIX(a, return gen_to_std_device(M, static_cast<DeviceMatrix<DT>&>(*l->m));)
+}
+
+int dlaf_mi355x_reduction_to_band_device(dlaf_mi355x_matrix_t a, int band, void* taus) noexcept {
+  WITH_MATRIX(a, return reduction_to_band_device(M, band, static_cast<DT*>(taus));)
+}
+int dlaf_mi355x_bt_reduction_to_band_device(int band, dlaf_mi355x_gmatrix_t c, dlaf_mi355x_matrix_t v,
+                                            const void* taus) noexcept {
+  if (!c || !c->m || !v || !v->m || c->m->type != v->type)
+    return -1;
+  WITH_MATRIX(v, return bt_reduction_to_band_device(band, static_cast<GeneralMatrix<DT>&>(*c->m).m, M,
+                                                    static_cast<const DT*>(taus));)
 }
 
 int dlaf_mi355x_matrix_trsm_profile(dlaf_mi355x_matrix_t h, int reps, double* ms, double* flops, double* bytes) noexcept {

@@ -1,0 +1,572 @@
+// red2band.cpp -- reduction of a Hermitian matrix to band form, Q^H A Q = B, and the matching
+// back-transformation C <- Q C (first stage of the eigensolver of BASELINE
+// configuration 5).
+//
+// Reference: dlaf::eigensolver::internal::reduction_to_band (include/dlaf/eigensolver/reduction_to_band.h:40-122),
+// ReductionToBand::call local (eigensolver/reduction_to_band/impl.h:968-1110) and distributed (:1113-1462);
+// bt_reduction_to_band (eigensolver/bt_reduction_to_band.h, impl.h:132-370).  Per panel of `band` columns the
+// reference: copies the panel to the HOST and computes its Householder reflectors there with a thread team
+// (:881-961, :297-361), forms T (t_factor_impl.h), W = V T, X = A W tile by tile with partial sums reduced
+// over both communicators (:692-807), W2 = W^H X, X -= 1/2 V W2, broadcasts x / v row- and column-wise and
+// updates the trailing matrix with her2k / gemm tile tasks (:810-852).
+//
+// MI355X design.  The matrix stays in the tile layout of the Cholesky path (lower tiles), everything else is
+// organised around REPLICATED, ZERO-EXTENDED PANELS: V, W and X are column-major arrays that cover the global
+// rows [e0, n), e0 = the origin of the tile row that holds the first row r0 of the panel, with zeros in
+// [e0, r0).  With that
+//   * the trailing update A -= X V^H + V X^H is ONE launch of the Cholesky path's two-segment her2k update
+//     kernel over whole tiles (the rows / columns in front of r0 subtract exact zeros): no sub-tile views;
+//   * X = A W is one launch of tile_panel_kernel over the lower tiles (each tile used straight and
+//     conjugate-transposed) + one reduction of the partial layers;
+//   * on a process grid every rank holds the whole panels, so the reference's six row / column panel
+//     broadcasts and two tile-wise reductions per step collapse into: an all-gather of the panel's tile rows
+//     inside the owning process column, one row broadcast of the factored panel (+ taus), one all-reduce of X.
+//     T, W, W2 and the X update are recomputed by every rank from the replicated panels (b x b work).  The panel
+//     itself is factored redundantly by the ranks of the owning process column from the gathered copy: ONE
+//     cooperative kernel (panel_qr_kernel) instead of a per-reflector reduction over the column communicator.
+// One stream, no lookahead yet (DESIGN.md says what that costs).
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "../device/band_api.hpp"
+#include "red2band.hpp"
+#include "runtime.hpp"
+#include "tile_matrix.hpp"
+
+namespace dlaf_mi355x {
+
+namespace {
+template <class T>
+T* dalloc(size_t elems) {
+  T* p = nullptr;
+  DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(elems, 1) * sizeof(T)));
+  return p;
+}
+template <class T>
+T scalar(double re) {
+  return make_host_el<T>(re);
+}
+
+double g_last_ms = 0, g_last_flops = 0;
+}  // namespace
+
+void red2band_last_profile(double* ms, double* flops) {
+  if (ms)
+    *ms = g_last_ms;
+  if (flops)
+    *flops = g_last_flops;
+}
+
+int get_band_size(int nb) {
+  // eigensolver/internal/get_band_size.h:20-31 with the default eigensolver_min_band = 100 (tune.h)
+  constexpr int min_band = 100;
+  for (int div = nb / min_band; div >= 2; --div)
+    if (nb % div == 0)
+      return nb / div;
+  return nb;
+}
+
+template <class T>
+int reduction_to_band_device(DeviceMatrix<T>& A, int band, T* taus_host) {
+  if (A.transposed)
+    fatal("[dlaf_mi355x] reduction_to_band: the matrix must be held as uplo = L (the reference references the lower "
+          "triangle only, reduction_to_band.h:66-68)\n");
+  if (band < 2 || A.nb % band != 0)
+    fatal("[dlaf_mi355x] reduction_to_band: band_size %d must be >= 2 and divide the block size %d\n", band, A.nb);
+  Grid* grid = A.grid;
+  Transport* tr = grid_transport(*grid);
+  const bool dist = grid->nranks > 1;
+  if (dist && !tr)
+    fatal("[dlaf_mi355x] grid with %d ranks has no transport\n", grid->nranks);
+  const Axis& rows = A.rows;
+  const Axis& cols = A.cols;
+  const long n = A.n, nt = A.nt, ltr = A.ltr, ltc = A.ltc;
+  const int nb = A.nb, b = band;
+  const size_t te = A.tile_elems;
+  hipStream_t s = A.s_high;
+  int* info = A.info;
+  DLAF_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int), s));
+  const long nrefls = std::max<long>(0, n - b - 1);
+  if (nrefls == 0) {
+    DLAF_HIP_CHECK(hipStreamSynchronize(s));
+    return 0;
+  }
+  const long npanels = (nrefls - 1) / b + 1;
+  const long ldp = ((n + 15) / 16) * 16;
+
+  // ---- workspaces --------------------------------------------------------------------------------------------
+  T* qt = dalloc<T>((size_t) b * (size_t) n);
+  T* V = dalloc<T>((size_t) ldp * b);
+  T* W = dalloc<T>((size_t) ldp * b);
+  T* X = dalloc<T>((size_t) ldp * b);
+  T* S = dalloc<T>((size_t) b * b);
+  T* Tm = dalloc<T>((size_t) b * b);
+  T* W2 = dalloc<T>((size_t) b * b);
+  T* taus = dalloc<T>((size_t) nrefls + 1);
+  DLAF_HIP_CHECK(hipMemsetAsync(V, 0, (size_t) ldp * b * sizeof(T), s));
+  DLAF_HIP_CHECK(hipMemsetAsync(W, 0, (size_t) ldp * b * sizeof(T), s));
+  DLAF_HIP_CHECK(hipMemsetAsync(X, 0, (size_t) ldp * b * sizeof(T), s));
+  DLAF_HIP_CHECK(hipMemsetAsync(taus, 0, ((size_t) nrefls + 1) * sizeof(T), s));
+  const int ksplit_max = std::max(1, gemm_pick_ksplit<T>(b, b, n));
+  T* gpart = dalloc<T>(gemm_partial_elems<T>(b, b, ksplit_max));
+  // partial layers of the xHEMM: layers(out tiles) * out tiles at its maximum over the panels
+  long cap_s = 1, cap_t = 1;
+  for (long ot = 1; ot <= std::max<long>(ltr, 1); ++ot)
+    cap_s = std::max<long>(cap_s, (long) tile_panel_pick_layers(ot, nb, b, std::max<long>(ltc, 1), sizeof(T)) * ot);
+  for (long ot = 1; ot <= std::max<long>(ltc, 1); ++ot)
+    cap_t = std::max<long>(cap_t, (long) tile_panel_pick_layers(ot, nb, b, std::max<long>(ltr, 1), sizeof(T)) * ot);
+  T* part_s = dalloc<T>((size_t) cap_s * nb * (size_t) b);
+  T* part_t = dalloc<T>((size_t) cap_t * nb * (size_t) b);
+  void* qr_scratch = nullptr;
+  DLAF_HIP_CHECK(hipMalloc(&qr_scratch, panel_qr_scratch_bytes(b, sizeof(T))));
+
+  hipEvent_t ev0, ev1;
+  DLAF_HIP_CHECK(hipEventCreate(&ev0));
+  DLAF_HIP_CHECK(hipEventCreate(&ev1));
+  DLAF_HIP_CHECK(hipEventRecord(ev0, s));
+
+  const CommAxis ax_row = CommAxis::Row, ax_col = CommAxis::Col;
+  for (long p = 0; p < npanels; ++p) {
+    if (tr)
+      tr->mark(p);
+    const long r0 = (p + 1) * b, c0 = p * b;
+    const int nr = (int) std::min<long>(b, nrefls - c0);
+    if (nr <= 0)
+      break;
+    const long I0 = r0 / nb, e0 = I0 * nb, J0 = c0 / nb;
+    const long me = n - e0, m = n - r0, o = r0 - e0;
+    const int cc = (int) (c0 % nb);
+    const long il0 = rows.next_local(I0), jl0 = cols.next_local(I0);
+    const int pcol = cols.owner(J0);
+    const bool in_pcol = cols.rank == pcol;
+    // ---- 1. the panel, transposed, gathered inside the owning process column ------------------------------------
+    if (in_pcol) {
+      const long jlp = cols.local_of(J0);
+      launch_panel_move(A.tiles, ltr, nb, (int) il0, (int) ltr, (int) jlp, rows.P, rows.shift(), (int) nt,
+                        rows.last_extent(), cc, b, qt, e0, r0, true, s);
+      if (rows.P > 1) {
+        tr->group_begin();
+        for (long I = I0; I < nt; ++I)
+          tr->bcast(ax_col, rows.owner(I), rows.rank, qt + (size_t) (I * nb - e0) * b, qt + (size_t) (I * nb - e0) * b,
+                    (size_t) rows.tile_extent(I) * b * sizeof(T), s);
+        tr->group_end();
+      }
+      // ---- 2. reflectors (xGEQR2 without the size-1 reflector) ---------------------------------------------------
+      launch_panel_qr(qt + (size_t) o * b, m, b, nr, taus + c0, qr_scratch, info, s);
+      launch_panel_move(A.tiles, ltr, nb, (int) il0, (int) ltr, (int) jlp, rows.P, rows.shift(), (int) nt,
+                        rows.last_extent(), cc, b, qt, e0, r0, false, s);
+    }
+    if (cols.P > 1) {
+      tr->bcast(ax_row, pcol, cols.rank, qt, qt, (size_t) me * b * sizeof(T), s);
+      tr->bcast(ax_row, pcol, cols.rank, taus + c0, taus + c0, (size_t) nr * sizeof(T), s);
+    }
+    // ---- 3. well-formed V, T factor, W = V T  (every rank, from the replicated panel) ------------------------
+    launch_make_v(qt, b, nr, e0, r0, n, V, ldp, s);
+    {
+      GemmArgs<T> g;
+      g.M = b;
+      g.N = b;
+      g.K = (int) me;
+      g.a = V;
+      g.lda = ldp;
+      g.opa = 'C';
+      g.b = V;
+      g.ldb = ldp;
+      g.opb = 'N';
+      g.c = S;
+      g.ldc = b;
+      g.alpha = scalar<T>(1.0);
+      g.beta = scalar<T>(0.0);
+      g.ksplit = std::min(ksplit_max, gemm_pick_ksplit<T>(b, b, me));
+      g.partial = gpart;
+      launch_gemm(g, s);
+    }
+    DLAF_HIP_CHECK(hipMemsetAsync(Tm, 0, (size_t) b * b * sizeof(T), s));
+    launch_tfactor(S, (long) b, taus + c0, nr, Tm, (long) b, s);
+    {
+      GemmArgs<T> g;
+      g.M = (int) me;
+      g.N = b;
+      g.K = b;
+      g.a = V;
+      g.lda = ldp;
+      g.opa = 'N';
+      g.b = Tm;
+      g.ldb = b;
+      g.opb = 'N';
+      g.c = W;
+      g.ldc = ldp;
+      g.alpha = scalar<T>(1.0);
+      g.beta = scalar<T>(0.0);
+      launch_gemm(g, s);
+    }
+    // ---- 4. X = A_t W (xHEMM on the lower tiles), summed over the grid -------------------------------------------
+    TilePanelArgs<T> h;
+    h.tiles = A.tiles;
+    h.ltr = ltr;
+    h.nb = nb;
+    h.il0 = (int) il0;
+    h.il1 = (int) ltr;
+    h.jl0 = (int) jl0;
+    h.jl1 = (int) ltc;
+    h.pr = rows.P;
+    h.ri = rows.shift();
+    h.pc = cols.P;
+    h.ci = cols.shift();
+    h.nt_r = (int) nt;
+    h.last_rows = rows.last_extent();
+    h.nt_c = (int) nt;
+    h.last_cols = cols.last_extent();
+    h.herm = 1;
+    h.w = W;
+    h.ldw = ldp;
+    h.e0 = e0;
+    h.ncols = b;
+    h.kinds = 3;
+    h.layers_s = tile_panel_pick_layers(ltr - il0, nb, b, std::max<long>(ltc - jl0, 1), sizeof(T));
+    h.layers_t = tile_panel_pick_layers(ltc - jl0, nb, b, std::max<long>(ltr - il0, 1), sizeof(T));
+    h.part_s = part_s;
+    h.part_t = part_t;
+    launch_tile_panel(h, s);
+    launch_hemm_reduce(h, r0, X, ldp, s);
+    if (dist)
+      tr->allreduce_sum(X, (size_t) ldp * b, TypeInfo<T>::tag, 'A', s);
+    // ---- 5. W2 = W^H X,  X -= 1/2 V W2 -----------------------------------------------------------------------------
+    {
+      GemmArgs<T> g;
+      g.M = b;
+      g.N = b;
+      g.K = (int) me;
+      g.a = W;
+      g.lda = ldp;
+      g.opa = 'C';
+      g.b = X;
+      g.ldb = ldp;
+      g.opb = 'N';
+      g.c = W2;
+      g.ldc = b;
+      g.alpha = scalar<T>(1.0);
+      g.beta = scalar<T>(0.0);
+      g.ksplit = std::min(ksplit_max, gemm_pick_ksplit<T>(b, b, me));
+      g.partial = gpart;
+      launch_gemm(g, s);
+    }
+    {
+      GemmArgs<T> g;
+      g.M = (int) me;
+      g.N = b;
+      g.K = b;
+      g.a = V;
+      g.lda = ldp;
+      g.opa = 'N';
+      g.b = W2;
+      g.ldb = b;
+      g.opb = 'N';
+      g.c = X;
+      g.ldc = ldp;
+      g.alpha = scalar<T>(-0.5);
+      g.beta = scalar<T>(1.0);
+      launch_gemm(g, s);
+    }
+    // ---- 6. A_t -= X V^H + V X^H on the lower tiles (tile::her2k / 2 x tile::gemm, impl.h:545-585) ----------------
+    if (il0 < ltr && jl0 < ltc) {
+      UpdateArgs<T> ua;
+      ua.c = A.tiles;
+      ua.c_tsr = (long) te;
+      ua.c_tsc = (long) (te * ltr);
+      ua.ldc = nb;
+      ua.a = X + (rows.global_of(il0) * nb - e0);
+      ua.a2 = V + (rows.global_of(il0) * nb - e0);
+      ua.a_ts = (long) rows.P * nb;
+      ua.lda = (int) ldp;
+      ua.b = V + (cols.global_of(jl0) * nb - e0);
+      ua.b2 = X + (cols.global_of(jl0) * nb - e0);
+      ua.b_ts = (long) cols.P * nb;
+      ua.ldb = (int) ldp;
+      ua.il0 = (int) il0;
+      ua.il1 = (int) ltr;
+      ua.jl0 = (int) jl0;
+      ua.jl1 = (int) ltc;
+      ua.nb = nb;
+      ua.K1 = b;
+      ua.K = 2 * b;
+      ua.her2k = 1;
+      ua.pr = rows.P;
+      ua.ri = rows.shift();
+      ua.pc = cols.P;
+      ua.ci = cols.shift();
+      ua.nt = (int) nt;
+      ua.last_rows = rows.last_extent();
+      ua.info = info;
+      launch_update(ua, s, 3);
+    }
+    if (dist)
+      DLAF_HIP_CHECK(hipStreamSynchronize(s));
+  }
+  DLAF_HIP_CHECK(hipEventRecord(ev1, s));
+  int h_info = 0;
+  DLAF_HIP_CHECK(hipMemcpyAsync(&h_info, info, sizeof(int), hipMemcpyDeviceToHost, s));
+  if (taus_host)
+    DLAF_HIP_CHECK(hipMemcpyAsync(taus_host, taus, (size_t) nrefls * sizeof(T), hipMemcpyDeviceToHost, s));
+  DLAF_HIP_CHECK(hipStreamSynchronize(s));
+  float ms = 0;
+  DLAF_HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
+  g_last_ms = ms;
+  g_last_flops = (TypeInfo<T>::is_complex ? 4.0 : 1.0) * 4.0 / 3.0 * (double) n * (double) n * (double) n;
+  DLAF_HIP_CHECK(hipEventDestroy(ev0));
+  DLAF_HIP_CHECK(hipEventDestroy(ev1));
+  for (T* q : {qt, V, W, X, S, Tm, W2, taus, gpart, part_s, part_t})
+    DLAF_HIP_CHECK(hipFree(q));
+  DLAF_HIP_CHECK(hipFree(qr_scratch));
+  if (h_info == kInfoSchedulingFailure)
+    fatal("[dlaf_mi355x] reduction_to_band: the cooperative panel kernel could not make progress (its workgroups were "
+          "not co-resident)\n");
+  return h_info;
+}
+
+// Host entry: a = this process's local column-major part of the Hermitian matrix (lower triangle referenced),
+// overwritten with the band + reflectors; taus: n - band - 1 values, all of them on every rank
+template <class T>
+int reduction_to_band_host(Grid* g, T* a, long lda, long n, int nb, int isrc, int jsrc, int band, T* taus) {
+  DeviceMatrix<T> A;
+  A.create(g, 'L', n, nb, isrc, jsrc);
+  A.upload(a, lda);
+  const int r = reduction_to_band_device(A, band, taus);
+  A.download(a, lda, true);
+  return r;
+}
+
+
+// ------------------------------------------------------------------------------------------------ back-transformation
+// C <- Q C with Q = H_0 H_1 ... (the reflectors reduction_to_band left below the band of A), applied in blocks of nb
+// reflectors, last block first (bt_reduction_to_band/impl.h:132-236 local, :239-370 distributed):
+//     W = V T^H,   W2 = W^H C,   C -= V W2.
+// C: n x k general matrix in tile layout with A's block size and row distribution.  Same replicated, zero-extended
+// panels as above; W2 = W^H C runs as the adjoint kind of tile_panel_kernel over the tiles of C (its result W2^H is
+// summed over the process column), C -= V W2 as one rectangular launch of the Cholesky update kernel.
+template <class T>
+int bt_reduction_to_band_device(int band, TileMatrix<T>& C, DeviceMatrix<T>& A, const T* taus_host) {
+  if (A.transposed)
+    fatal("[dlaf_mi355x] bt_reduction_to_band: the reflectors must be held as uplo = L\n");
+  if (C.grid != A.grid || C.nb != A.nb || C.rows.n != A.n || C.rows.src != A.rows.src || C.transposed)
+    fatal("[dlaf_mi355x] bt_reduction_to_band: C must have A's block size, row count and row source rank\n");
+  Grid* grid = A.grid;
+  Transport* tr = grid_transport(*grid);
+  const bool dist = grid->nranks > 1;
+  if (dist && !tr)
+    fatal("[dlaf_mi355x] grid with %d ranks has no transport\n", grid->nranks);
+  const Axis& rows = A.rows;
+  const Axis& cols = A.cols;
+  const Axis& ccols = C.cols;
+  const long n = A.n, nt = A.nt, ltr = A.ltr;
+  const int nb = A.nb, b = band;
+  const size_t te = A.tile_elems;
+  hipStream_t s = A.s_high;
+  int* info = A.info;
+  DLAF_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int), s));
+  const long total = n - b - 1;
+  const long cltc = C.ltc, cltr = C.ltr;
+  if (total <= 0 || ccols.n == 0) {
+    DLAF_HIP_CHECK(hipStreamSynchronize(s));
+    return 0;
+  }
+  const long nblocks = (total - 1) / nb + 1;
+  const long ldp = ((n + 15) / 16) * 16;
+  const long ldw2 = std::max<long>(cltc * nb, 1);
+
+  T* qt = dalloc<T>((size_t) nb * (size_t) n);
+  T* V = dalloc<T>((size_t) ldp * nb);
+  T* W = dalloc<T>((size_t) ldp * nb);
+  T* S = dalloc<T>((size_t) nb * nb);
+  T* Tm = dalloc<T>((size_t) nb * nb);
+  T* W2H = dalloc<T>((size_t) ldw2 * nb);
+  T* taus = dalloc<T>((size_t) total + 1);
+  DLAF_HIP_CHECK(hipMemcpyAsync(taus, taus_host, (size_t) total * sizeof(T), hipMemcpyHostToDevice, s));
+  DLAF_HIP_CHECK(hipMemsetAsync(V, 0, (size_t) ldp * nb * sizeof(T), s));
+  DLAF_HIP_CHECK(hipMemsetAsync(W, 0, (size_t) ldp * nb * sizeof(T), s));
+  const int ksplit_max = std::max(1, gemm_pick_ksplit<T>(nb, nb, n));
+  T* gpart = dalloc<T>(gemm_partial_elems<T>(nb, nb, ksplit_max));
+  long lay_cap = 1;
+  for (long ot = 1; ot <= std::max<long>(cltc, 1); ++ot)
+    lay_cap = std::max<long>(lay_cap, (long) tile_panel_pick_layers(ot, nb, nb, std::max<long>(cltr, 1), sizeof(T)) * ot);
+  T* part_t = dalloc<T>((size_t) lay_cap * nb * (size_t) nb);
+
+  hipEvent_t ev0, ev1;
+  DLAF_HIP_CHECK(hipEventCreate(&ev0));
+  DLAF_HIP_CHECK(hipEventCreate(&ev1));
+  DLAF_HIP_CHECK(hipEventRecord(ev0, s));
+
+  const CommAxis ax_row = CommAxis::Row, ax_col = CommAxis::Col;
+  for (long k = nblocks - 1; k >= 0; --k) {
+    if (tr)
+      tr->mark(k);
+    const int nrefl = (int) std::min<long>(nb, total - k * nb);
+    const long r0 = k * nb + b, c0 = k * nb;
+    const long I0 = r0 / nb, e0 = I0 * nb, J0 = k;
+    const long me = n - e0;
+    const long il0 = rows.next_local(I0);
+    const int pcol = cols.owner(J0);
+    const bool in_pcol = cols.rank == pcol;
+    if (in_pcol) {
+      const long jlp = cols.local_of(J0);
+      launch_panel_move(A.tiles, ltr, nb, (int) il0, (int) ltr, (int) jlp, rows.P, rows.shift(), (int) nt,
+                        rows.last_extent(), 0, nrefl, qt, e0, r0, true, s);
+      if (rows.P > 1) {
+        tr->group_begin();
+        for (long I = I0; I < nt; ++I)
+          tr->bcast(ax_col, rows.owner(I), rows.rank, qt + (size_t) (I * nb - e0) * nrefl,
+                    qt + (size_t) (I * nb - e0) * nrefl, (size_t) rows.tile_extent(I) * nrefl * sizeof(T), s);
+        tr->group_end();
+      }
+    }
+    if (cols.P > 1)
+      tr->bcast(ax_row, pcol, cols.rank, qt, qt, (size_t) me * nrefl * sizeof(T), s);
+    launch_make_v(qt, nrefl, nrefl, e0, r0, n, V, ldp, s);
+    {
+      GemmArgs<T> g;
+      g.M = nrefl;
+      g.N = nrefl;
+      g.K = (int) me;
+      g.a = V;
+      g.lda = ldp;
+      g.opa = 'C';
+      g.b = V;
+      g.ldb = ldp;
+      g.opb = 'N';
+      g.c = S;
+      g.ldc = nb;
+      g.alpha = scalar<T>(1.0);
+      g.beta = scalar<T>(0.0);
+      g.ksplit = std::min(ksplit_max, gemm_pick_ksplit<T>(nrefl, nrefl, me));
+      g.partial = gpart;
+      launch_gemm(g, s);
+    }
+    launch_tfactor(S, (long) nb, taus + c0, nrefl, Tm, (long) nb, s);
+    {
+      GemmArgs<T> g;  // W = V T^H
+      g.M = (int) me;
+      g.N = nrefl;
+      g.K = nrefl;
+      g.a = V;
+      g.lda = ldp;
+      g.opa = 'N';
+      g.b = Tm;
+      g.ldb = nb;
+      g.opb = 'C';
+      g.c = W;
+      g.ldc = ldp;
+      g.alpha = scalar<T>(1.0);
+      g.beta = scalar<T>(0.0);
+      launch_gemm(g, s);
+    }
+    if (cltc > 0) {
+      // W2^H = C^H W over the local tiles of C with global tile row >= I0
+      TilePanelArgs<T> h;
+      h.tiles = C.tiles;
+      h.ltr = cltr;
+      h.nb = nb;
+      h.il0 = (int) il0;
+      h.il1 = (int) cltr;
+      h.jl0 = 0;
+      h.jl1 = (int) cltc;
+      h.pr = rows.P;
+      h.ri = rows.shift();
+      h.pc = ccols.P;
+      h.ci = ccols.shift();
+      h.nt_r = (int) nt;
+      h.last_rows = rows.last_extent();
+      h.nt_c = (int) ccols.nt();
+      h.last_cols = ccols.last_extent();
+      h.herm = 0;
+      h.w = W;
+      h.ldw = ldp;
+      h.e0 = e0;
+      h.ncols = nrefl;
+      h.kinds = 2;
+      h.layers_t = tile_panel_pick_layers(cltc, nb, nrefl, std::max<long>(cltr - il0, 1), sizeof(T));
+      h.part_t = part_t;
+      if (il0 < cltr) {
+        launch_tile_panel(h, s);
+        launch_layers_reduce(part_t, h.layers_t, cltc * nb, nrefl, W2H, ldw2, s);
+      }
+      else {
+        DLAF_HIP_CHECK(hipMemsetAsync(W2H, 0, (size_t) ldw2 * nrefl * sizeof(T), s));
+      }
+      if (rows.P > 1)
+        tr->allreduce_sum(W2H, (size_t) ldw2 * nrefl, TypeInfo<T>::tag, 'C', s);
+      // C -= V W2 = V (W2^H)^H
+      if (il0 < cltr) {
+        UpdateArgs<T> ua;
+        ua.c = C.tiles;
+        ua.c_tsr = (long) te;
+        ua.c_tsc = (long) (te * cltr);
+        ua.ldc = nb;
+        ua.a = V + (rows.global_of(il0) * nb - e0);
+        ua.a_ts = (long) rows.P * nb;
+        ua.lda = (int) ldp;
+        ua.b = W2H;
+        ua.b_ts = (long) nb;
+        ua.ldb = (int) ldw2;
+        ua.il0 = (int) il0;
+        ua.il1 = (int) cltr;
+        ua.jl0 = 0;
+        ua.jl1 = (int) cltc;
+        ua.nb = nb;
+        ua.K = nrefl;
+        ua.pr = rows.P;
+        ua.ri = rows.shift();
+        ua.pc = ccols.P;
+        ua.ci = ccols.shift();
+        ua.nt = (int) nt;
+        ua.last_rows = rows.last_extent();
+        ua.info = info;
+        ua.rect = 1;
+        ua.nt_c = (int) ccols.nt();
+        ua.last_cols = ccols.last_extent();
+        launch_update(ua, s, 3);
+      }
+    }
+    if (dist)
+      DLAF_HIP_CHECK(hipStreamSynchronize(s));
+  }
+  DLAF_HIP_CHECK(hipEventRecord(ev1, s));
+  DLAF_HIP_CHECK(hipStreamSynchronize(s));
+  float ms = 0;
+  DLAF_HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
+  g_last_ms = ms;
+  g_last_flops = (TypeInfo<T>::is_complex ? 4.0 : 1.0) * 2.0 * (double) n * (double) n * (double) ccols.n;
+  DLAF_HIP_CHECK(hipEventDestroy(ev0));
+  DLAF_HIP_CHECK(hipEventDestroy(ev1));
+  for (T* q : {qt, V, W, S, Tm, W2H, taus, gpart, part_t})
+    DLAF_HIP_CHECK(hipFree(q));
+  return 0;
+}
+
+template <class T>
+int bt_reduction_to_band_host(Grid* g, int band, T* c, long ldc, long ncols_c, int c_jsrc, const T* a, long lda, long n,
+                              int nb, int isrc, int jsrc, const T* taus) {
+  DeviceMatrix<T> A;
+  A.create(g, 'L', n, nb, isrc, jsrc);
+  A.upload(a, lda);
+  TileMatrix<T> C;
+  C.create(g, false, n, ncols_c, nb, isrc, c_jsrc);
+  C.upload(c, ldc, false, false, T{}, A.s_high);
+  const int r = bt_reduction_to_band_device(band, C, A, taus);
+  C.download(c, ldc, false, A.s_high);
+  DLAF_HIP_CHECK(hipStreamSynchronize(A.s_high));
+  return r;
+}
+
+#define INST(T)                                                           \
+  template int reduction_to_band_device<T>(DeviceMatrix<T>&, int, T*);    \
+  template int reduction_to_band_host<T>(Grid*, T*, long, long, int, int, int, int, T*); \
+  template int bt_reduction_to_band_device<T>(int, TileMatrix<T>&, DeviceMatrix<T>&, const T*); \
+  template int bt_reduction_to_band_host<T>(Grid*, int, T*, long, long, int, const T*, long, long, int, int, int, const T*);
+INST(float)
+INST(double)
+INST(cfloat)
+INST(cdouble)
+#undef INST
+
+}  // namespace dlaf_mi355x

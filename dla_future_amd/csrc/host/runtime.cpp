@@ -99,6 +99,50 @@ public:
     }
   }
 
+  void allreduce_sum(void* dev, size_t count, char type, char scope, hipStream_t stream) override {
+    if (count == 0)
+      return;
+    const bool dbl = (type == 'd' || type == 'z');
+    const size_t nreal = count * ((type == 'c' || type == 'z') ? 2 : 1);
+    const size_t bytes = nreal * (dbl ? sizeof(double) : sizeof(float));
+    reserve(2 * bytes);
+    DLAF_HIP_CHECK(hipStreamSynchronize(stream));
+    DLAF_HIP_CHECK(hipMemcpy(pinned_, dev, bytes, hipMemcpyDeviceToHost));
+    char* mine = static_cast<char*>(pinned_);
+    char* tmp = mine + bytes;
+    std::vector<char> acc(bytes);
+    for (int pass = 0; pass < 2; ++pass) {
+      // pass 0: along my process row (axis Row), pass 1: along my process column
+      if ((pass == 0 && scope == 'C') || (pass == 1 && scope == 'R'))
+        continue;
+      const int members = pass == 0 ? npcol : nprow, me = pass == 0 ? mycol : myrow;
+      if (members <= 1)
+        continue;
+      for (int root = 0; root < members; ++root) {
+        if (me == root)
+          std::memcpy(tmp, mine, bytes);
+        if (bcast_(user_, pass, root, tmp, bytes) != 0)
+          fatal("[dlaf_mi355x] host broadcast callback failed\n");
+        if (root == 0)
+          std::memcpy(acc.data(), tmp, bytes);
+        else if (dbl) {
+          double* a = reinterpret_cast<double*>(acc.data());
+          const double* t = reinterpret_cast<const double*>(tmp);
+          for (size_t i = 0; i < nreal; ++i)
+            a[i] += t[i];
+        }
+        else {
+          float* a = reinterpret_cast<float*>(acc.data());
+          const float* t = reinterpret_cast<const float*>(tmp);
+          for (size_t i = 0; i < nreal; ++i)
+            a[i] += t[i];
+        }
+      }
+      std::memcpy(mine, acc.data(), bytes);
+    }
+    DLAF_HIP_CHECK(hipMemcpy(dev, mine, bytes, hipMemcpyHostToDevice));
+  }
+
 private:
   void reserve(size_t bytes) {
     if (bytes <= cap_)
@@ -128,7 +172,7 @@ public:
   bool device_side() const override { return inner_->device_side(); }
   void bcast(CommAxis axis, int root, int my_index, const void* send, void* recv, size_t bytes,
              hipStream_t stream) override {
-    if (bytes != 0)
+    if (bytes != 0 && g_->comm_log_on)
       g_->comm_log.push_back({(long) axis, (long) root, (long) bytes, (long) depth_});
     inner_->bcast(axis, root, my_index, send, recv, bytes, stream);
   }
@@ -141,14 +185,28 @@ public:
     inner_->group_end();
   }
   void barrier(hipStream_t stream) override {
-    g_->comm_log.push_back({3, 0, 0, 0});
+    if (g_->comm_log_on)
+      g_->comm_log.push_back({3, 0, 0, 0});
     inner_->barrier(stream);
   }
   void allreduce_max(double* v, int n, int nprow, int npcol, int myrow, int mycol) override {
-    g_->comm_log.push_back({4, 0, (long) (n * sizeof(double)), 0});
+    if (g_->comm_log_on)
+      g_->comm_log.push_back({4, 0, (long) (n * sizeof(double)), 0});
     inner_->allreduce_max(v, n, nprow, npcol, myrow, mycol);
   }
-  void mark(long step) override { g_->comm_log.push_back({2, step, 0, 0}); }
+  void allreduce_sum(void* dev, size_t count, char type, char scope, hipStream_t stream) override {
+    if (g_->comm_log_on)
+      g_->comm_log.push_back({4, (long) scope, (long) count, 0});
+    inner_->nprow = nprow;
+    inner_->npcol = npcol;
+    inner_->myrow = myrow;
+    inner_->mycol = mycol;
+    inner_->allreduce_sum(dev, count, type, scope, stream);
+  }
+  void mark(long step) override {
+    if (g_->comm_log_on)
+      g_->comm_log.push_back({2, step, 0, 0});
+  }
   bool is_recorder() const { return true; }
 
 private:
@@ -163,6 +221,12 @@ Transport* grid_transport(Grid& g) {
     g.transport = make_host_transport(g.host_bcast, g.host_barrier, g.host_user);
   if (g.transport && g.comm_log_on && dynamic_cast<RecordingTransport*>(g.transport.get()) == nullptr)
     g.transport = std::unique_ptr<Transport>(new RecordingTransport(std::move(g.transport), &g));
+  if (g.transport) {
+    g.transport->nprow = g.nprow;
+    g.transport->npcol = g.npcol;
+    g.transport->myrow = g.myrow;
+    g.transport->mycol = g.mycol;
+  }
   return g.transport.get();
 }
 

@@ -54,8 +54,15 @@ public:
   // max over every rank of the grid of n host doubles (the reference's sync::reduce with MPI_MAX in
   // max_norm, include/dlaf/auxiliary/norm/mc.h); result on every rank
   virtual void allreduce_max(double* host_vals, int n, int nprow, int npcol, int myrow, int mycol) = 0;
+  // element-wise SUM of a device buffer over the ranks of a communicator, in place, result on every member
+  // (the reference's schedule_all_reduce_in_place / schedule_reduce_* with MPI_SUM, communication/kernels/
+  // all_reduce.h, reduce.h).  type: s, d, c, z; scope: 'A' the whole grid, 'R' my process row, 'C' my process column.
+  // Every member ends up with the same bits (the host transport sums in root order, RCCL's ring does too).
+  virtual void allreduce_sum(void* dev_buf, size_t count, char type, char scope, hipStream_t stream) = 0;
   // step marker of the executor (a no-op for real transports; the recording wrapper logs it)
   virtual void mark(long /*step*/) {}
+  // the grid this transport serves (set by grid_transport)
+  int nprow = 1, npcol = 1, myrow = 0, mycol = 0;
 };
 
 // One communication event as the recording transport logs it (dlaf_mi355x_grid_comm_log_*): what the

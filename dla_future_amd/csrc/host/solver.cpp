@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "runtime.hpp"
+#include "tile_matrix.hpp"
 
 namespace dlaf_mi355x {
 
@@ -48,97 +49,6 @@ T* dev_alloc(size_t elems) {
   DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), elems * sizeof(T)));
   return p;
 }
-
-// General block-cyclic matrix in device tile layout (nb x nb tiles, tile (il,jl) at (il + jl*ltr) nb^2).
-template <class T>
-struct TileMatrix {
-  Grid* grid = nullptr;
-  bool transposed = false;  // the view is the (conjugate-)transpose of the caller's matrix
-  Axis rows, cols;          // axes of the VIEW
-  int nb = 1;
-  long ltr = 0, ltc = 0;
-  size_t tile_elems = 0;
-  T* tiles = nullptr;
-  T* staging = nullptr;
-  bool owns = true;  // false: `tiles` belongs to somebody else (a view over a resident matrix)
-
-  // m_src x n_src: global size of the caller's matrix, (isrc, jsrc) its source process
-  void create(Grid* g, bool transposed_, long m_src, long n_src, int nb_, int isrc, int jsrc, T* borrow = nullptr) {
-    grid = g;
-    transposed = transposed_;
-    nb = nb_;
-    Axis srow{m_src, nb, g->nprow, g->myrow, isrc};
-    Axis scol{n_src, nb, g->npcol, g->mycol, jsrc};
-    rows = transposed ? scol : srow;
-    cols = transposed ? srow : scol;
-    ltr = rows.local_tiles();
-    ltc = cols.local_tiles();
-    tile_elems = (size_t) nb * nb;
-    owns = borrow == nullptr;
-    tiles = owns ? dev_alloc<T>((size_t) ltr * ltc * tile_elems) : borrow;
-  }
-  ~TileMatrix() {
-    if (tiles && owns)
-      (void) hipFree(tiles);
-    if (staging)
-      (void) hipFree(staging);
-  }
-  T* tile(long il, long jl) const { return tiles + (size_t) (il + jl * ltr) * tile_elems; }
-  // physical grid dimension (0: process rows, 1: process columns) the view's rows / columns are spread over
-  int row_dim() const { return transposed ? 1 : 0; }
-  int col_dim() const { return transposed ? 0 : 1; }
-
-  LayoutArgs<T> layout(T* cm, long ld) const {
-    LayoutArgs<T> a;
-    a.tiles = tiles;
-    a.cm = cm;
-    a.ld_cm = ld;
-    a.ltr = (int) ltr;
-    a.ltc = (int) ltc;
-    a.nb = nb;
-    a.rows = rows.local_size();
-    a.cols = cols.local_size();
-    a.pr = rows.P;
-    a.ri = rows.shift();
-    a.pc = cols.P;
-    a.ci = cols.shift();
-    a.transpose = transposed ? 1 : 0;
-    a.full = 1;
-    return a;
-  }
-  void source_extents(long& srows, long& scols) const {
-    srows = transposed ? cols.local_size() : rows.local_size();
-    scols = transposed ? rows.local_size() : cols.local_size();
-  }
-  void upload(const T* host, long ld, bool conj, bool scale, T alpha, hipStream_t s) {
-    long srows, scols;
-    source_extents(srows, scols);
-    if (srows == 0 || scols == 0)
-      return;
-    if (!staging)
-      staging = dev_alloc<T>((size_t) srows * scols);
-    DLAF_HIP_CHECK(hipMemcpy2DAsync(staging, (size_t) srows * sizeof(T), host, (size_t) ld * sizeof(T),
-                                    (size_t) srows * sizeof(T), (size_t) scols, hipMemcpyHostToDevice, s));
-    LayoutArgs<T> a = layout(staging, srows);
-    a.conj = conj ? 1 : 0;
-    a.scale = scale ? 1 : 0;
-    a.alpha = alpha;
-    launch_to_tiles(a, s);
-  }
-  void download(T* host, long ld, bool conj, hipStream_t s) {
-    long srows, scols;
-    source_extents(srows, scols);
-    if (srows == 0 || scols == 0)
-      return;
-    if (!staging)
-      staging = dev_alloc<T>((size_t) srows * scols);
-    LayoutArgs<T> a = layout(staging, srows);
-    a.conj = conj ? 1 : 0;
-    launch_from_tiles(a, s);
-    DLAF_HIP_CHECK(hipMemcpy2DAsync(host, (size_t) ld * sizeof(T), staging, (size_t) srows * sizeof(T),
-                                    (size_t) srows * sizeof(T), (size_t) scols, hipMemcpyDeviceToHost, s));
-  }
-};
 
 template <class T>
 T conj_el(T v) {
@@ -568,12 +478,6 @@ int triangular_solver_host(Grid* g, char side, char uplo, char op, char diag, T 
 
 // ================================================================================ device-resident operands
 // A general m x n matrix resident in HBM in tile layout (the right-hand sides of a solve), behind an opaque handle.
-template <class T>
-struct GeneralMatrix : MatrixBase {
-  TileMatrix<T> m;
-  long rows_g = 0, cols_g = 0;
-  int isrc = 0, jsrc = 0;
-};
 
 MatrixBase* general_matrix_create(Grid* g, char type, long m, long n, int nb, int isrc, int jsrc) {
   runtime_init();

@@ -77,6 +77,15 @@ public:
     std::memcpy(host_vals, scal_host_, sizeof(double) * (size_t) n);
   }
 
+  void allreduce_sum(void* dev, size_t count, char type, char scope, hipStream_t stream) override {
+    if (count == 0)
+      return;
+    const bool dbl = (type == 'd' || type == 'z');
+    const size_t nreal = count * ((type == 'c' || type == 'z') ? 2 : 1);
+    ncclComm_t c = scope == 'R' ? row_ : scope == 'C' ? col_ : world_;
+    DLAF_NCCL_CHECK(ncclAllReduce(dev, dev, nreal, dbl ? ncclDouble : ncclFloat, ncclSum, c, stream));
+  }
+
 private:
   static constexpr int kScalars = 16;
   ncclComm_t world_ = nullptr, row_ = nullptr, col_ = nullptr;

@@ -197,6 +197,47 @@ DLAF_EXTERN_C void dlaf_mi355x_pzhegst(int ibtype, char uplo, int n, dlaf_comple
 DLAF_EXTERN_C int dlaf_mi355x_generalized_to_standard_device(dlaf_mi355x_matrix_t a,
                                                              dlaf_mi355x_matrix_t cholesky_factor_of_b) DLAF_NOEXCEPT;
 
+/* ---- reduction to band + back-transformation (first stage of the eigensolver) ----------- */
+/* dlaf::eigensolver::internal::reduction_to_band<B, D, T>(grid, mat_a, band_size)
+ * (include/dlaf/eigensolver/reduction_to_band.h:40-122; the reference has no C entry for the stage alone):
+ * Q^H A Q = B with B Hermitian band (main diagonal + band_size sub-diagonals).  a: this process's local
+ * column-major part of the Hermitian matrix; only its LOWER triangle is referenced and overwritten -- with the band
+ * and, below it, the Householder reflectors (the layout of reduction_to_band.h:77-96); the strict upper triangle is
+ * untouched.  band_size >= 2 must divide the (square) block size.  taus: n - band_size - 1 scalar factors, ALL of
+ * them on every process (the reference returns them distributed over the process columns, replicated over the
+ * rows; entry j belongs to the reflector in global column j).  Returns 0. */
+DLAF_EXTERN_C int dlaf_mi355x_reduction_to_band_s(int context, float* a, struct DLAF_descriptor desca, int band_size,
+                                                  float* taus) DLAF_NOEXCEPT;
+DLAF_EXTERN_C int dlaf_mi355x_reduction_to_band_d(int context, double* a, struct DLAF_descriptor desca, int band_size,
+                                                  double* taus) DLAF_NOEXCEPT;
+DLAF_EXTERN_C int dlaf_mi355x_reduction_to_band_c(int context, dlaf_complex_c* a, struct DLAF_descriptor desca,
+                                                  int band_size, dlaf_complex_c* taus) DLAF_NOEXCEPT;
+DLAF_EXTERN_C int dlaf_mi355x_reduction_to_band_z(int context, dlaf_complex_z* a, struct DLAF_descriptor desca,
+                                                  int band_size, dlaf_complex_z* taus) DLAF_NOEXCEPT;
+/* the same on a device-resident matrix (created with uplo 'L'); taus: host array as above (may be NULL) */
+DLAF_EXTERN_C int dlaf_mi355x_reduction_to_band_device(dlaf_mi355x_matrix_t a, int band_size, void* taus) DLAF_NOEXCEPT;
+/* dlaf::eigensolver::internal::bt_reduction_to_band(grid, band_size, mat_c, mat_v, mat_taus)
+ * (include/dlaf/eigensolver/bt_reduction_to_band.h): C <- Q C with the reflectors reduction_to_band left in v (lower
+ * triangle, below the band) and its taus.  c: n x k general matrix with v's block size and row distribution. */
+DLAF_EXTERN_C int dlaf_mi355x_bt_reduction_to_band_s(int context, int band_size, float* c, struct DLAF_descriptor descc,
+                                                     const float* v, struct DLAF_descriptor descv,
+                                                     const float* taus) DLAF_NOEXCEPT;
+DLAF_EXTERN_C int dlaf_mi355x_bt_reduction_to_band_d(int context, int band_size, double* c, struct DLAF_descriptor descc,
+                                                     const double* v, struct DLAF_descriptor descv,
+                                                     const double* taus) DLAF_NOEXCEPT;
+DLAF_EXTERN_C int dlaf_mi355x_bt_reduction_to_band_c(int context, int band_size, dlaf_complex_c* c,
+                                                     struct DLAF_descriptor descc, const dlaf_complex_c* v,
+                                                     struct DLAF_descriptor descv, const dlaf_complex_c* taus) DLAF_NOEXCEPT;
+DLAF_EXTERN_C int dlaf_mi355x_bt_reduction_to_band_z(int context, int band_size, dlaf_complex_z* c,
+                                                     struct DLAF_descriptor descc, const dlaf_complex_z* v,
+                                                     struct DLAF_descriptor descv, const dlaf_complex_z* taus) DLAF_NOEXCEPT;
+/* get_band_size (include/dlaf/eigensolver/internal/get_band_size.h:20-31, eigensolver_min_band = 100): the band the
+ * reference's eigensolver picks for a block size (128 for nb = 512) */
+DLAF_EXTERN_C int dlaf_mi355x_get_band_size(int nb) DLAF_NOEXCEPT;
+/* device time (ms, HIP events) and whole-grid algorithmic flops (4/3 n^3, resp. 2 n^2 k; x4 complex) of the last
+ * reduction_to_band / bt_reduction_to_band on this process */
+DLAF_EXTERN_C int dlaf_mi355x_red2band_profile(double* ms, double* flops) DLAF_NOEXCEPT;
+
 /* Device-resident operands: a general m x n matrix in HBM (tile layout; square blocks) as the right-hand side,
  * a dlaf_mi355x_matrix_t (the uplo triangle of a resident matrix, e.g. the factor dlaf_mi355x_cholesky_* left there)
  * as the triangular matrix.  b is overwritten by the solution; nothing crosses PCIe.  potrs_device = the two solves of
@@ -210,6 +251,9 @@ DLAF_EXTERN_C int dlaf_mi355x_gmatrix_download(dlaf_mi355x_gmatrix_t m, void* ho
 DLAF_EXTERN_C int dlaf_mi355x_triangular_solver_device(char side, char uplo, char op, char diag, const void* alpha,
                                                        dlaf_mi355x_matrix_t a, dlaf_mi355x_gmatrix_t b) DLAF_NOEXCEPT;
 DLAF_EXTERN_C int dlaf_mi355x_potrs_device(char uplo, dlaf_mi355x_matrix_t factor, dlaf_mi355x_gmatrix_t b) DLAF_NOEXCEPT;
+/* bt_reduction_to_band on resident operands: c (general matrix) <- Q c, reflectors in v (uplo 'L'), taus on the host */
+DLAF_EXTERN_C int dlaf_mi355x_bt_reduction_to_band_device(int band_size, dlaf_mi355x_gmatrix_t c, dlaf_mi355x_matrix_t v,
+                                                          const void* taus) DLAF_NOEXCEPT;
 
 /* Device time (ms, HIP events on the compute stream) of the sweep of the last triangular solve on this process
  * -- relayout and PCIe staging excluded -- and the whole-grid algorithmic flops it stands for (m n^2 for side

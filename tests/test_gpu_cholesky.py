@@ -50,10 +50,8 @@ def schedule(request, monkeypatch):
     return request.param
 
 
-@pytest.mark.parametrize("t", TYPES)
-@pytest.mark.parametrize("uplo", ["L", "U"])
-def test_cholesky_random_vs_oracle(dlaf, grid, oracle, t, uplo, schedule):
-    for n, nb in [(300, 64), (515, 128), (1024, 256), (64, 64), (100, 64), (129, 64), (200, 32)]:
+def _random_vs_oracle(dlaf, grid, oracle, t, uplo, sizes):
+    for n, nb in sizes:
         dt = oracle.DTYPES[t]
         a0 = oracle.set_random_hpd(n, nb, dt)
         ref = a0.copy(order="F")
@@ -67,6 +65,21 @@ def test_cholesky_random_vs_oracle(dlaf, grid, oracle, t, uplo, schedule):
         other0 = np.triu(a0, 1) if uplo == "L" else np.tril(a0, -1)
         assert np.array_equal(other, other0)
         assert oracle.cholesky_residual(uplo, a0, got) <= n * oracle.eps_of(dt)
+
+
+# Covering set (round 3: the full product schedule x type x uplo x 7 sizes took a third of the GPU suite): every
+# issue order x {d, z} x {L, U} on three sizes (ragged small block, 16-aligned fast path, one-tile edge), and
+# s / c -- which share every code path but the element type -- on the default order over the full size list.
+@pytest.mark.parametrize("t", ["d", "z"])
+@pytest.mark.parametrize("uplo", ["L", "U"])
+def test_cholesky_random_vs_oracle(dlaf, grid, oracle, t, uplo, schedule):
+    _random_vs_oracle(dlaf, grid, oracle, t, uplo, [(515, 128), (1024, 256), (129, 64)])
+
+
+@pytest.mark.parametrize("t", TYPES)
+@pytest.mark.parametrize("uplo", ["L", "U"])
+def test_cholesky_random_vs_oracle_default_schedule(dlaf, grid, oracle, t, uplo):
+    _random_vs_oracle(dlaf, grid, oracle, t, uplo, [(300, 64), (515, 128), (64, 64), (100, 64), (200, 32)])
 
 
 def test_generator_matches_oracle(dlaf, grid, oracle):
