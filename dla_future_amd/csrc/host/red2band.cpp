@@ -223,7 +223,8 @@ int reduction_to_band_device(DeviceMatrix<T>& A, int band, T* taus_host) {
     h.ldw = ldp;
     h.e0 = e0;
     h.ncols = b;
-    h.kinds = 3;
+    // (a rank without local trailing rows or columns has no work items at all: nothing to sum either)
+    h.kinds = (il0 < ltr && jl0 < ltc) ? 3 : 0;
     h.layers_s = tile_panel_pick_layers(ltr - il0, nb, b, std::max<long>(ltc - jl0, 1), sizeof(T));
     h.layers_t = tile_panel_pick_layers(ltc - jl0, nb, b, std::max<long>(ltr - il0, 1), sizeof(T));
     h.part_s = part_s;

@@ -271,6 +271,54 @@ def main():
                 if not good:
                     print(f"[dist_worker] gen_to_std random FAILED {t}{uplo} n={n} nb={nb}: max diff {md} tol {tol}", flush=True)
                 ok &= bool(good)
+        # reduction_to_band + bt_reduction_to_band on the grid: the reference's distributed test
+        # (test_reduction_to_band.cpp:405-489 -- its size lists on the 6-rank grids, checkResult: Q B Q^H == A within
+        # n^2 * error, the upper triangle untouched) plus fast-path sizes, a non-zero source rank, elementwise against
+        # the oracle's restatement of ReductionToBand::call; then C <- Q C against the oracle (test_bt_reduction_to_band.cpp)
+        from oracle import red2band as rb
+        for t, n, nb, band, src in [("d", 13, 3, 3, 0), ("d", 24, 3, 3, 1), ("d", 40, 5, 5, 0), ("z", 42, 6, 3, 1), ("d", 29, 9, 3, 0),
+                                    ("s", 42, 12, 4, 0), ("c", 27, 9, 3, 1), ("d", 4, 4, 2, 0), ("d", 300, 64, 32, 1),
+                                    ("z", 260, 64, 32, 0), ("d", 515, 128, 64, 1), ("d", 0, 6, 2, 0)]:
+            dt = oracle.DTYPES[t]
+            sr, sc = (max(0, nprow - 1), min(1, npcol - 1)) if src else (0, 0)
+            a0 = rb.random_hermitian(n, dt, seed=300 + n)
+            poisoned = a0.copy(order="F")
+            poisoned[np.triu_indices(n, 1)] = -9.9
+            la = np.asfortranarray(oracle.scatter(poisoned, nb, nprow, npcol, sr, sc, extra_ld=1)[(grid.myrow, grid.mycol)])
+            taus = dlaf.reduction_to_band(grid, la, nb, band, sr, sc, n=n)
+            got = gather_global(la, grid, n, nb, sr, sc, oracle)
+            all_taus = [None] * dist.get_world_size()
+            dist.all_gather_object(all_taus, taus)
+            good = all(np.array_equal(all_taus[0], x) for x in all_taus)   # replicated, bit for bit
+            if rank == 0 and n:
+                good &= bool((got[np.triu_indices(n, 1)] == dt(-9.9)).all())
+                okc, diff, tol = rb.check_result(a0, got, taus, band)
+                ref = a0.copy(order="F")
+                rtaus = rb.reduction_to_band(ref, nb, band)
+                dm = np.abs(np.tril(ref) - np.tril(got)).max()
+                good &= bool(okc) and dm <= tol and (len(taus) == 0 or np.abs(rtaus - taus).max() <= tol)
+                if not good:
+                    print(f"[dist_worker] reduction_to_band FAILED {t} n={n} nb={nb} band={band} src=({sr},{sc}) grid "
+                          f"{nprow}x{npcol}: checkResult diff {diff} tol {tol}, vs oracle {dm}", flush=True)
+            ok &= bool(good)
+            # back-transformation with these reflectors
+            k = max(1, (2 * n) // 3 + 1)
+            rng = np.random.default_rng(11)
+            c0 = rng.uniform(-1, 1, (n, k)) + (1j * rng.uniform(-1, 1, (n, k)) if t in "cz" else 0)
+            c0 = np.asfortranarray(c0.astype(dt))
+            csc = min(npcol - 1, 1) if src else 0
+            lc = np.asfortranarray(oracle.scatter(c0, nb, nprow, npcol, sr, csc, extra_ld=2)[(grid.myrow, grid.mycol)])
+            dlaf.bt_reduction_to_band(grid, band, lc, la, taus, nb, sr, sc, csc, n=n, k=k)
+            gotc = gather_global(lc, grid, k, nb, sr, csc, oracle, m=n)
+            if rank == 0 and n:
+                refc = c0.copy(order="F")
+                rb.bt_reduction_to_band(refc, got, taus, nb, band)
+                tolc = max(1, n) * max(1, k) * rb.error_of(dt)
+                goodc = bool(np.abs(gotc - refc).max() <= tolc)
+                if not goodc:
+                    print(f"[dist_worker] bt_reduction_to_band FAILED {t} n={n} nb={nb} band={band} k={k} grid {nprow}x{npcol}: "
+                          f"max diff {np.abs(gotc - refc).max()} tol {tolc}", flush=True)
+                ok &= goodc
         # p?potrf -> p?potrs on resident matrices over the grid (no host staging between the factorization and the
         # two solves), and one resident solve per side against the oracle
         for t, uplo, n, nrhs, nb in [("d", "L", 300, 90, 32), ("z", "U", 200, 70, 32)]:
