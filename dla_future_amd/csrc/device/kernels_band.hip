@@ -18,6 +18,7 @@
 //   * the small movers: panel <-> tiles (transposing through LDS), well-formed V, T factor.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "band_api.hpp"
 #include "device_api.hpp"
@@ -141,22 +142,35 @@ __global__ __launch_bounds__(GenCfg<T>::type::THREADS, 2) void gemm_kernel(GemmA
   }
 }
 
+// grid: x = chunk of 4 * kThreads elements of a block, y = output block
 template <class T>
 __global__ __launch_bounds__(kThreads) void gemm_reduce_kernel(GemmArgs<T> p, GemmMap mp) {
   using Cfg = typename GenCfg<T>::type;
-  const int bm = blockIdx.x % mp.MB, bn = blockIdx.x / mp.MB;
+  const int bm = blockIdx.y % mp.MB, bn = blockIdx.y / mp.MB;
   const int m0 = bm * Cfg::BM, n0 = bn * Cfg::BN;
   const int mrows = min(Cfg::BM, p.M - m0), ncols = min(Cfg::BN, p.N - n0);
   const bool has_beta = !el_is_zero(p.beta);
-  for (int e = threadIdx.x; e < Cfg::BM * Cfg::BN; e += kThreads) {
+  const size_t blk = (size_t) (Cfg::BM * Cfg::BN);
+  for (int e = blockIdx.x * kThreads + threadIdx.x; e < Cfg::BM * Cfg::BN; e += gridDim.x * kThreads) {
     const int m = e % Cfg::BM, n = e / Cfg::BM;
     if (m >= mrows || n >= ncols)
       continue;
-    T s = zero_el<T>();
-    for (int ks = 0; ks < mp.KS; ++ks)
-      s = el_add(s, p.partial[((size_t) (ks * mp.NB + bn) * mp.MB + bm) * (size_t) (Cfg::BM * Cfg::BN) + e]);
+    // (fixed order; four partial sums in flight)
+    T s0 = zero_el<T>(), s1 = zero_el<T>(), s2 = zero_el<T>(), s3 = zero_el<T>();
+    int ks = 0;
+    for (; ks + 3 < mp.KS; ks += 4) {
+      const size_t o = ((size_t) (ks * mp.NB + bn) * mp.MB + bm) * blk + e;
+      const size_t st = (size_t) mp.NB * mp.MB * blk;
+      s0 = el_add(s0, p.partial[o]);
+      s1 = el_add(s1, p.partial[o + st]);
+      s2 = el_add(s2, p.partial[o + 2 * st]);
+      s3 = el_add(s3, p.partial[o + 3 * st]);
+    }
+    for (; ks < mp.KS; ++ks)
+      s0 = el_add(s0, p.partial[((size_t) (ks * mp.NB + bn) * mp.MB + bm) * blk + e]);
+    const T sum = el_add(el_add(s0, s1), el_add(s2, s3));
     T* c = p.c + (m0 + m) + (long) (n0 + n) * p.ldc;
-    T r = el_mul(p.alpha, s);
+    T r = el_mul(p.alpha, sum);
     if (has_beta)
       r = el_add(r, el_mul(p.beta, *c));
     *c = r;
@@ -379,42 +393,98 @@ __global__ __launch_bounds__(kThreads) void zero_rows_kernel(T* x, long ldx, lon
 }
 
 // ======================================================================================= T factor
-constexpr int kTfMax = 1024;
+constexpr int kTfMax = 1024;  // 4 rows of 1024 complex doubles = 64 KiB of LDS
 
-// one workgroup; t_j = T(0:j, 0:j) * (-tau_j S(0:j, j)), T(j, j) = tau_j (t_factor_impl.h:60-131)
+// T(j, j) = tau_j,  t_j = T(0:j, 0:j) (-tau_j S(0:j, j))  (t_factor_impl.h:60-131), written ROW-wise: row i of T needs
+// only itself, S and taus --  T(i, j) = -tau_j sum_{l=i}^{j-1} T(i, l) S(l, j)  for j > i -- so the k rows are k
+// independent waves (4 per workgroup), each a chain of k - i dot products whose operand column S(:, j+1) is fetched
+// while the dot product of column j is being reduced.  The row lives in LDS (one value per column).
+constexpr int kTfU = 8;  // prefetch registers per lane: columns of up to 64 * kTfU rows (larger k: no prefetch)
+
+template <class T>
+__device__ __forceinline__ T wave_sum(T v) {
+  using R = real_t<T>;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    if constexpr (TypeInfo<T>::is_complex) {
+      v.re += __shfl_xor(v.re, off);
+      v.im += __shfl_xor(v.im, off);
+    }
+    else
+      v += __shfl_xor(v, off);
+  }
+  (void) sizeof(R);
+  return v;
+}
+
 template <class T>
 __global__ __launch_bounds__(kThreads) void tfactor_kernel(const T* s, long lds_, const T* taus, int k, T* t, long ldt) {
-  __shared__ T tmp[kTfMax];
-  for (int j = 0; j < k; ++j) {
-    const T tau = taus[j];
-    for (int i = threadIdx.x; i < j; i += kThreads)
-      tmp[i] = el_neg(el_mul(tau, s[i + (long) j * lds_]));
-    __syncthreads();
-    for (int i = threadIdx.x; i < k; i += kThreads) {
-      T a = zero_el<T>();
-      if (i < j) {
-        for (int l = i; l < j; ++l)
-          a = el_add(a, el_mul(t[i + (long) l * ldt], tmp[l]));
-      }
-      else if (i == j)
-        a = tau;
-      t[i + (long) j * ldt] = a;
+  extern __shared__ __attribute__((aligned(16))) unsigned char tf_raw[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (kThreads / 64) + wave;
+  if (i >= k)
+    return;  // (no workgroup barrier below: waves are independent)
+  T* row = reinterpret_cast<T*>(tf_raw) + (size_t) wave * k;
+  for (int j = lane; j < i; j += 64)
+    t[i + (long) j * ldt] = zero_el<T>();
+  if (lane == 0)
+    row[i] = taus[i];
+  const bool pre = (k - i) <= 64 * kTfU;
+  T nxt[kTfU];
+  auto fetch = [&](int j) {
+#pragma unroll
+    for (int u = 0; u < kTfU; ++u) {
+      const int l = i + lane + 64 * u;
+      nxt[u] = (l < j) ? s[l + (long) j * lds_] : zero_el<T>();
     }
-    __threadfence_block();
-    __syncthreads();
+  };
+  if (pre && i + 1 < k)
+    fetch(i + 1);
+  for (int j = i + 1; j < k; ++j) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    T acc = zero_el<T>();
+    if (pre) {
+      T cur[kTfU];
+#pragma unroll
+      for (int u = 0; u < kTfU; ++u)
+        cur[u] = nxt[u];
+      if (j + 1 < k)
+        fetch(j + 1);
+#pragma unroll
+      for (int u = 0; u < kTfU; ++u) {
+        const int l = i + lane + 64 * u;
+        if (l < j)
+          acc = el_add(acc, el_mul(row[l], cur[u]));
+      }
+    }
+    else {
+      for (int l = i + lane; l < j; l += 64)
+        acc = el_add(acc, el_mul(row[l], s[l + (long) j * lds_]));
+    }
+    acc = wave_sum(acc);
+    if (lane == 0)
+      row[j] = el_neg(el_mul(taus[j], acc));
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  for (int j = i + lane; j < k; j += 64)
+    t[i + (long) j * ldt] = row[j];
 }
 
 // ======================================================================================= panel QR
 constexpr int kQrMaxWg = 128;
-constexpr int kQrMaxColsPerThread = 2;  // b <= 512
+constexpr int kQrDefaultWg = 128;  // most workgroups of a panel (DLAF_MI355X_QR_MAXWG): more = less work per exchange but G^2 partial-sum traffic
+constexpr int kQrMaxColsPerThread = 2;  // b <= 512 (columns per thread: kernel template parameter CPT)
+template <class T, int NT>
+constexpr int qr_batch() {  // rows of a thread whose loads are in flight together (registers: batch x element size)
+  return (sizeof(T) >= 16 ? 8 : 16) / (NT > 512 ? 2 : 1);
+}
 constexpr long kQrSpinLimit = 20000000;
 
 struct QrMap {
   int nwg;
   int rows_per_wg;
   int ct;      // column threads (power of two)
-  int chunk;   // rows per LDS chunk
+  int wide;    // != 0: the partial-sum vectors are read in 16-byte words
   long spin_limit;
 };
 
@@ -445,180 +515,290 @@ __device__ __forceinline__ void qr_store_wt(T* p, const T& v) {
 //       y = -sign(re x0) |x|,  tau = (y - x0) / y,  scale = 1 / (x0 - y)                 (xLARFG, impl.h:106-140)
 //       w_c = conj(h_c) + scale (d_c - conj(h_c) x0)        (= P_t^H v with v = [1; scale x],  impl.h:143-185)
 //   and updates its rows:  P[r, c] -= conj(tau) v_r conj(w_c)  (impl.h:188-228), P[r, j] = v_r, P[j, j] = y,
-//   accumulating the partial sums of step j + 1 in the same pass.
-// Hand-offs: write-through stores + drained flag / relaxed poll + one acquire (the protocol of the tile POTRF).
-template <class T>
-__global__ __launch_bounds__(kThreads) void panel_qr_kernel(T* qt, long m, int b, int nr, T* taus, T* partial,
+//   accumulating the partial sums of step j + 1 in the same pass.  A thread owns a column (CPT of them when b > 256):
+//   its element of a row is a coalesced global access, the two values of the row every column needs (x_r and the old
+//   P[r, j+1]) are staged in LDS before any of them is overwritten.  The row loop is branch-light on purpose: a first
+//   version with a branch per row and 64-bit row arithmetic spent 12 of its 23 us per reflector issuing instructions.
+// Hand-offs: write-through stores + drained counter / relaxed poll + one acquire (the protocol of the tile POTRF).
+template <class T, int CPT, int NT>
+__global__ __launch_bounds__(NT) void panel_qr_kernel(T* qt, long m, int b, int nr, T* taus, T* partial,
                                                             unsigned* counters, int* info, QrMap mp) {
   using R = real_t<T>;
+  constexpr int kB = qr_batch<T, NT>();
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  T* chunk = reinterpret_cast<T*>(lds_raw);                 // [chunk rows][b]
-  T* red = chunk + (size_t) mp.chunk * b;                   // [rg][b]
-  T* wv = red + (size_t) max(kThreads / mp.ct, 2) * b;    // [b]  (red doubles as [d | h] in the exchange)
-  T* sc = wv + b;                                           // tau, scale, y
+  const int nrg = NT / mp.ct;
+  const int redrows = max(max(nrg, 8), mp.wide ? NT / (int) ((size_t) b * sizeof(T) / 16) : 0);
+  T* red = reinterpret_cast<T*>(lds_raw);          // [redrows][b]: row-group / load-group partial sums, then d | h
+  T* wv = red + (size_t) redrows * b;              // [b]
+  T* sc = wv + b;                                  // conj(tau), scale, y, pad
+  // x[parity][0/1][rows_per_wg]: columns j and j + 1 of my rows as they are BEFORE reflector j is applied (indexed by
+  // r - row_lo).  A pass reads the buffers of its parity and -- from the threads that own columns j + 1 and j + 2,
+  // which have just computed them -- fills those of the next step: no reload from memory, no extra round trip.
+  T* xbuf = sc + 4;
   __shared__ unsigned flag_slot;
   const int g = blockIdx.x;
-  const long row_lo = (long) g * mp.rows_per_wg;
-  const long row_hi = min(m, row_lo + mp.rows_per_wg);
-  const int tc = threadIdx.x % mp.ct, rg = threadIdx.x / mp.ct, nrg = kThreads / mp.ct;
-  T dnext[kQrMaxColsPerThread];
-
-  // one pass over the rows of this workgroup: apply reflector j (j >= 0) and sum the dots of column j + 1
-  auto pass = [&](int j, const T ctau, const T scale, const T y) {
+  // (32-bit row arithmetic: the launcher keeps m * b below 2^31)
+  const int row_lo = g * mp.rows_per_wg;
+  const int row_hi = min((int) m, row_lo + mp.rows_per_wg);
+  const int tc = threadIdx.x % mp.ct, rg = threadIdx.x / mp.ct;
+#ifdef DLAF_QR_STAMPS
+  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = wall_clock64();
+#define QR_STAMP(k)                                  \
+  do {                                               \
+    const unsigned long long tn_ = wall_clock64();   \
+    st[k] += tn_ - tprev;                            \
+    tprev = tn_;                                     \
+  } while (0)
+#else
+#define QR_STAMP(k)
+#endif
+  // one loop, one copy of every phase: j = -1 is the opening pass that only sums the dots of column 0
+  for (int j = -1; j < nr; ++j) {
+    T ctau = zero_el<T>(), scale = zero_el<T>(), y = zero_el<T>();
+    if (j >= 0) {
+      // ---- exchange: wait for every workgroup's share of column j ----------------------------------------------
+      if (threadIdx.x == 0) {
+        unsigned v;
+        long spins = 0;
+        while ((v = __hip_atomic_load(&counters[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (unsigned) mp.nwg) {
+          __builtin_amdgcn_s_sleep(1);
+          ++spins;
+          if (spins > mp.spin_limit ||
+              ((spins & 1023) == 0 && __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            v = 0xFFFFFFFFu;
+            break;
+          }
+        }
+        QR_STAMP(0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        flag_slot = v;
+      }
+      __syncthreads();
+      QR_STAMP(1);
+      if (flag_slot == 0xFFFFFFFFu) {
+        if (threadIdx.x == 0)
+          atomicCAS(info, 0, kInfoSchedulingFailure);
+        return;
+      }
+      // ---- totals: every workgroup adds the shares in the same order, so all of them form the same reflector ----
+      const T* part = partial + (size_t) (j & 1) * mp.nwg * (size_t) b;
+      T hrow[CPT];
 #pragma unroll
-    for (int u = 0; u < kQrMaxColsPerThread; ++u)
-      dnext[u] = zero_el<T>();
+      for (int u = 0; u < CPT; ++u) {
+        const int c = tc + u * mp.ct;
+        hrow[u] = (rg == 0 && c < b && c >= j) ? qt[j * b + c] : zero_el<T>();
+      }
+      int G;  // partial-sum rows in `red`
+      if (mp.wide) {
+        // 16-byte words: thread t takes word t % W of the vectors q = t / W, t / W + G, ...; eight loads in flight
+        typedef R rw __attribute__((ext_vector_type(16 / sizeof(R))));
+        constexpr int NR = 16 / (int) sizeof(R);
+        const int W = (int) ((size_t) b * sizeof(T) / 16);
+        G = NT / W;
+        const int w = threadIdx.x % W, grp = threadIdx.x / W;
+        rw acc0;
+#pragma unroll
+        for (int e = 0; e < NR; ++e)
+          acc0[e] = R(0);
+        const rw* base = reinterpret_cast<const rw*>(part) + w;
+        for (int q = grp; q < mp.nwg; q += 8 * G) {
+          rw v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int qq = min(q + e * G, mp.nwg - 1);
+            v[e] = base[(size_t) qq * W];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (q + e * G < mp.nwg)
+              acc0 += v[e];
+        }
+        reinterpret_cast<rw*>(red)[(size_t) grp * W + w] = acc0;
+      }
+      else {
+        G = nrg;
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+          const int c = tc + u * mp.ct;
+          if (c < b) {
+            T a0 = zero_el<T>();
+            if (c >= j)
+              for (int q = rg; q < mp.nwg; q += nrg)
+                a0 = el_add(a0, part[(size_t) q * b + c]);
+            red[(size_t) rg * b + c] = a0;
+          }
+        }
+      }
+      __syncthreads();
+      T dtot[CPT];
+#pragma unroll
+      for (int u = 0; u < CPT; ++u) {
+        const int c = tc + u * mp.ct;
+        dtot[u] = zero_el<T>();
+        if (rg == 0 && c < b) {
+          dtot[u] = red[c];
+          for (int q2 = 1; q2 < G; ++q2)
+            dtot[u] = el_add(dtot[u], red[(size_t) q2 * b + c]);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < CPT; ++u) {
+        const int c = tc + u * mp.ct;
+        if (rg == 0 && c < b) {
+          red[c] = dtot[u];      // d_c
+          red[b + c] = hrow[u];  // h_c
+        }
+      }
+      __syncthreads();
+      QR_STAMP(2);
+      // ---- the reflector's scalars, w ---------------------------------------------------------------------------
+      if (threadIdx.x == 0) {
+        const T x0 = red[b + j];
+        const R nrm2 = re_of(red[j]);
+        // (a reflector with |x| == 0 is the identity: tau = 0 and the column stays as it is, impl.h:108-109 -- with
+        // scale 1 and conj(tau) 0 the pass below rewrites every element with its own value)
+        T tau = zero_el<T>(), sc1 = make_el<T>(R(1), R(0)), yy = x0;
+        if (nrm2 != R(0)) {
+          const R nrm = sqrt(nrm2);
+          const R yr = __builtin_signbit(re_of(x0)) ? nrm : -nrm;
+          yy = make_el<T>(yr, R(0));
+          tau = el_scale(el_sub(yy, x0), R(1) / yr);
+          sc1 = el_inv(el_sub(x0, yy));
+        }
+        sc[0] = el_conj(tau);
+        sc[1] = sc1;
+        sc[2] = yy;
+        if (g == 0)
+          taus[j] = tau;
+      }
+      __syncthreads();
+      ctau = sc[0];
+      scale = sc[1];
+      y = sc[2];
+      {
+        const T x0 = red[b + j];
+        for (int c = threadIdx.x; c < b; c += NT) {
+          if (c <= j)
+            continue;
+          const T hc = el_conj(red[b + c]);
+          wv[c] = el_add(hc, el_mul(scale, el_sub(red[c], el_mul(hc, x0))));
+        }
+      }
+      __syncthreads();
+      QR_STAMP(3);
+    }
+    // ---- pass over my rows: apply reflector j, sum the dots of column j + 1 -------------------------------------
     const int jn = j + 1;
     const bool dots = jn < nr;
-    const long first = max(row_lo, (long) max(j, 0));
-    for (long rc = first; rc < row_hi; rc += mp.chunk) {
-      const int nrows = (int) min((long) mp.chunk, row_hi - rc);
-      // old values of the chunk -> LDS (columns >= max(j, 0))
-      for (int e = threadIdx.x; e < nrows * b; e += kThreads)
-        chunk[e] = qt[rc * b + e];
-      __syncthreads();
-      for (int rr = rg; rr < nrows; rr += nrg) {
-        const long r = rc + rr;
-        const T* row = chunk + (size_t) rr * b;
-        T vr = zero_el<T>();
-        T xn = zero_el<T>();
-        if (j >= 0) {
-          vr = (r == j) ? make_el<T>(R(1), R(0)) : el_mul(row[j], scale);
-          if (dots)
-            xn = el_sub(row[jn], el_mul(ctau, el_mul(vr, el_conj(wv[jn]))));
-        }
-        else if (dots)
-          xn = row[jn];
-#pragma unroll
-        for (int u = 0; u < kQrMaxColsPerThread; ++u) {
-          const int c = tc + u * mp.ct;
-          if (c >= b)
-            break;
-          if (j >= 0 && c < j)
-            continue;
-          T nv = row[c];
-          if (j >= 0) {
-            if (c == j)
-              nv = (r == j) ? y : vr;
-            else
-              nv = el_sub(nv, el_mul(ctau, el_mul(vr, el_conj(wv[c]))));
-            // the next head row is read by every workgroup after the next exchange
-            if (r == jn)
-              qr_store_wt(&qt[r * b + c], nv);
-            else
-              qt[r * b + c] = nv;
-          }
-          if (dots && c >= jn && r >= jn)
-            dnext[u] = el_add(dnext[u], el_mul(el_conj(nv), xn));
-        }
-      }
+    const bool upd = j >= 0;
+    const int first = max(row_lo, max(j, 0));
+    const int nrows = max(0, row_hi - first);
+    const int par = (j + 1) & 1;
+    const T* xs = xbuf + (size_t) (2 * par) * mp.rows_per_wg + (first - row_lo);       // column j
+    const T* xo = xbuf + (size_t) (2 * par + 1) * mp.rows_per_wg + (first - row_lo);   // column j + 1
+    T* xs_next = xbuf + (size_t) (2 * (par ^ 1)) * mp.rows_per_wg + (first - row_lo);      // column j + 1, updated
+    T* xo_next = xbuf + (size_t) (2 * (par ^ 1) + 1) * mp.rows_per_wg + (first - row_lo);  // column j + 2, updated
+    if (j < 0) {
+      // opening pass: column 0 from memory
+      T* xo_w = xbuf + (size_t) (2 * par + 1) * mp.rows_per_wg + (first - row_lo);
+      for (int rr = threadIdx.x; rr < nrows; rr += NT)
+        xo_w[rr] = dots ? qt[(first + rr) * b + jn] : zero_el<T>();
       __syncthreads();
     }
-  };
-
-  // combine the row groups and publish this workgroup's partial sums of column jn
-  auto publish = [&](int jn) {
+    const T wn = (upd && dots) ? el_conj(wv[jn]) : zero_el<T>();
+    T wc[CPT], dnext[CPT], head_v[CPT];
+    bool colact[CPT];
 #pragma unroll
-    for (int u = 0; u < kQrMaxColsPerThread; ++u) {
+    for (int u = 0; u < CPT; ++u) {
       const int c = tc + u * mp.ct;
-      if (c < b)
-        red[(size_t) rg * b + c] = dnext[u];
+      wc[u] = (upd && c < b && c > j) ? el_conj(wv[c]) : zero_el<T>();
+      dnext[u] = zero_el<T>();
+      head_v[u] = zero_el<T>();
+      colact[u] = c < b && c >= j;
     }
-    __syncthreads();
-    T* mine = partial + ((size_t) (jn & 1) * mp.nwg + g) * (size_t) b;
-    for (int c = threadIdx.x; c < b; c += kThreads) {
-      if (c < jn)
-        continue;
-      T sum = red[c];
-      for (int q = 1; q < nrg; ++q)
-        sum = el_add(sum, red[(size_t) q * b + c]);
-      qr_store_wt(&mine[c], sum);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0)
-      __hip_atomic_fetch_add(&counters[jn], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
-
-  pass(-1, zero_el<T>(), zero_el<T>(), zero_el<T>());
-  if (nr > 0)
-    publish(0);
-  for (int j = 0; j < nr; ++j) {
-    // ---- exchange: wait for every workgroup's share of column j ------------------------------------------
-    if (threadIdx.x == 0) {
-      unsigned v;
-      long spins = 0;
-      while ((v = __hip_atomic_load(&counters[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (unsigned) mp.nwg) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > mp.spin_limit || __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-          v = 0xFFFFFFFFu;
-          break;
+    bool head_hit = false;
+    const int rlast = max(nrows - 1, 0);
+    for (int rb = rg; rb < nrows; rb += nrg * kB) {
+      // the batch's elements first (independent loads, all in flight; rows past the end re-read the last one)
+      T old[kB][CPT];
+#pragma unroll
+      for (int e = 0; e < kB; ++e) {
+        const int r = first + min(rb + e * nrg, rlast);
+#pragma unroll
+        for (int u = 0; u < CPT; ++u)
+          old[e][u] = colact[u] ? qt[r * b + tc + u * mp.ct] : zero_el<T>();
+      }
+#pragma unroll
+      for (int e = 0; e < kB; ++e) {
+        const int rr = rb + e * nrg;
+        const int rrc = min(rr, rlast);
+        const int r = first + rr;
+        const bool rowact = rr < nrows;
+        const T vr = (r == j) ? make_el<T>(R(1), R(0)) : el_mul(xs[rrc], scale);
+        const T xn = el_sub(xo[rrc], el_mul(ctau, el_mul(vr, wn)));
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+          const int c = tc + u * mp.ct;
+          const T nvu = el_sub(old[e][u], el_mul(ctau, el_mul(vr, wc[u])));
+          const T nv = (upd && c == j) ? ((r == j) ? y : vr) : nvu;
+          if (rowact && colact[u] && upd && r != jn)
+            qt[r * b + c] = nv;
+          if (rowact && c == jn)
+            xs_next[rr] = nv;
+          if (rowact && c == jn + 1 && c < b)
+            xo_next[rr] = nv;
+          const bool is_head = rowact && colact[u] && r == jn;
+          head_v[u] = is_head ? nv : head_v[u];
+          head_hit = head_hit || is_head;
+          const bool dact = rowact && dots && c >= jn && c < b && r >= jn;
+          dnext[u] = dact ? el_add(dnext[u], el_mul(el_conj(nv), xn)) : dnext[u];
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    // the next head row is read by every workgroup after the next exchange: write-through
+    if (head_hit && upd) {
+#pragma unroll
+      for (int u = 0; u < CPT; ++u)
+        if (colact[u])
+          qr_store_wt(&qt[jn * b + tc + u * mp.ct], head_v[u]);
+    }
+    QR_STAMP(4);
+    // ---- publish my share of column j + 1 ---------------------------------------------------------------------------
+    if (dots) {
+#pragma unroll
+      for (int u = 0; u < CPT; ++u) {
+        const int c = tc + u * mp.ct;
+        if (c < b)
+          red[(size_t) rg * b + c] = dnext[u];
+      }
+      __syncthreads();
+      T* mine = partial + ((size_t) (jn & 1) * mp.nwg + g) * (size_t) b;
+      for (int c = threadIdx.x; c < b; c += NT) {
+        T sum = red[c];
+        for (int q = 1; q < nrg; ++q)
+          sum = el_add(sum, red[(size_t) q * b + c]);
+        qr_store_wt(&mine[c], c >= jn ? sum : zero_el<T>());
+      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      flag_slot = v;
-    }
-    __syncthreads();
-    if (flag_slot == 0xFFFFFFFFu) {
+      __syncthreads();
       if (threadIdx.x == 0)
-        atomicCAS(info, 0, kInfoSchedulingFailure);
-      return;
+        __hip_atomic_fetch_add(&counters[jn], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // ---- totals, head row, the reflector's scalars, w ---------------------------------------------------------
-    const T* part = partial + (size_t) (j & 1) * mp.nwg * (size_t) b;
-    for (int c = threadIdx.x; c < b; c += kThreads) {
-      if (c < j)
-        continue;
-      T d = zero_el<T>();
-      for (int q = 0; q < mp.nwg; ++q)
-        d = el_add(d, part[(size_t) q * b + c]);
-      red[c] = d;                   // d_c
-      red[b + c] = qt[(long) j * b + c];  // h_c  (nrg >= 1 rows of `red`: needs 2 b elements, see launcher)
+    else {
+      // (the stores of the last pass need no hand-off; the barrier keeps the LDS staging of a further pass away)
+      __syncthreads();
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const T x0 = red[b + j];
-      const R nrm2 = re_of(red[j]);
-      T tau = zero_el<T>(), scale = zero_el<T>(), y = x0;
-      if (nrm2 != R(0)) {
-        const R nrm = sqrt(nrm2);
-        const R yr = __builtin_signbit(re_of(x0)) ? nrm : -nrm;
-        y = make_el<T>(yr, R(0));
-        tau = el_scale(el_sub(y, x0), R(1) / yr);
-        scale = el_inv(el_sub(x0, y));
-      }
-      sc[0] = tau;
-      sc[1] = scale;
-      sc[2] = y;
-      if (g == 0)
-        taus[j] = tau;
-    }
-    __syncthreads();
-    const T tau = sc[0], scale = sc[1], y = sc[2];
-    {
-      const T x0 = red[b + j];
-      for (int c = threadIdx.x; c < b; c += kThreads) {
-        if (c <= j)
-          continue;
-        const T hc = el_conj(red[b + c]);
-        wv[c] = el_add(hc, el_mul(scale, el_sub(red[c], el_mul(hc, x0))));
-      }
-    }
-    __syncthreads();
-    // (a reflector with tau == 0 is the identity: the reference leaves the column as it is, impl.h:108-109)
-    const bool ident = el_is_zero(tau);
-    if (!ident || j + 1 < nr) {
-      if (ident) {
-        // no update, but the dots of the next column are still needed: a pass that changes nothing
-        pass(j, zero_el<T>(), make_el<T>(R(1), R(0)), red[b + j]);
-      }
-      else
-        pass(j, el_conj(tau), scale, y);
-    }
-    if (j + 1 < nr)
-      publish(j + 1);
+    QR_STAMP(5);
   }
+#ifdef DLAF_QR_STAMPS
+  if (threadIdx.x == 0 && (g == 0 || g == mp.nwg - 1) && nr > 0)
+    printf("[qr stamps] wg %d of %d rows/wg %d nr %d: us per step: spin %.2f fence+bar %.2f totals %.2f scalars+w %.2f pass %.2f publish %.2f\n",
+           g, mp.nwg, mp.rows_per_wg, nr, st[0] * 0.01 / nr, st[1] * 0.01 / nr, st[2] * 0.01 / nr, st[3] * 0.01 / nr,
+           st[4] * 0.01 / nr, st[5] * 0.01 / nr);
+#endif
+#undef QR_STAMP
 }
 
 }  // namespace
@@ -662,7 +842,8 @@ void launch_gemm(const GemmArgs<T>& a, hipStream_t stream) {
   hipLaunchKernelGGL((gemm_kernel<T>), dim3((unsigned) (mp.MB * mp.NB * mp.KS)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream,
                      a, mp);
   if (mp.KS > 1)
-    hipLaunchKernelGGL((gemm_reduce_kernel<T>), dim3((unsigned) (mp.MB * mp.NB)), dim3(kThreads), 0, stream, a, mp);
+    hipLaunchKernelGGL((gemm_reduce_kernel<T>), dim3((unsigned) ((Cfg::BM * Cfg::BN + kThreads - 1) / kThreads), (unsigned) (mp.MB * mp.NB)),
+                       dim3(kThreads), 0, stream, a, mp);
 }
 
 int tile_panel_pick_layers(long out_tiles, int nb, int ncols, long max_src, size_t elem_size) {
@@ -731,34 +912,66 @@ void launch_panel_qr(T* qt, long m, int b, int nr, T* taus, void* scratch, int* 
     fprintf(stderr, "[dlaf_mi355x] panel QR: band size %d exceeds the supported %d\n", b, kQrMaxColsPerThread * kThreads);
     abort();
   }
-  QrMap mp;
-  int ct = 1;
-  while (ct < b && ct < kThreads)
-    ct *= 2;
-  mp.ct = ct;
-  // LDS chunk of about 32 KiB
-  int chunk = (int) std::max<size_t>(1, (32 * 1024) / ((size_t) b * sizeof(T)));
-  chunk = std::min(chunk, 64);
-  const int nrg = kThreads / ct;
-  chunk = std::max(chunk, nrg);
-  mp.chunk = chunk;
-  static const int max_wg = [] {
-    const char* e = std::getenv("DLAF_MI355X_QR_MAXWG");  // tuning / debugging: 1 = the whole panel in one workgroup
-    const int v = e ? std::atoi(e) : kQrMaxWg;
-    return std::max(1, std::min(v, kQrMaxWg));
-  }();
-  long rows_per_wg = std::max<long>(64, (m + max_wg - 1) / max_wg);
-  rows_per_wg = ((rows_per_wg + chunk - 1) / chunk) * chunk;
-  mp.rows_per_wg = (int) rows_per_wg;
-  mp.nwg = (int) ((m + rows_per_wg - 1) / rows_per_wg);
-  mp.spin_limit = qr_spin_limit();
   T* partial = static_cast<T*>(scratch);
   unsigned* counters = reinterpret_cast<unsigned*>(static_cast<char*>(scratch) + 2 * (size_t) kQrMaxWg * (size_t) b * sizeof(T));
   (void) hipMemsetAsync(counters, 0, (size_t) (b + 1) * sizeof(unsigned), stream);
-  // LDS: chunk + red (max(nrg, 2) rows of b) + w + 4 scalars
-  const size_t lds = ((size_t) chunk * b + (size_t) std::max(nrg, 2) * b + b + 4) * sizeof(T);
-  hipLaunchKernelGGL((panel_qr_kernel<T>), dim3((unsigned) mp.nwg), dim3(kThreads), lds, stream, qt, m, b, nr, taus, partial,
-                     counters, info, mp);
+  const size_t vec_bytes = (size_t) b * sizeof(T);
+  static const int max_wg = [] {
+    const char* e = std::getenv("DLAF_MI355X_QR_MAXWG");  // tuning / debugging: 1 = the whole panel in one workgroup
+    const int v = e ? std::atoi(e) : kQrDefaultWg;
+    return std::max(1, std::min(v, kQrMaxWg));
+  }();
+  // 1024-thread workgroups for real panels (eight row groups at b = 128: a thread then has few rows, and the pass is
+  // bound by the latency of its one or two batches of loads), 256 threads for narrow ones
+  const bool big = b >= 64;
+  const int nt = big ? 1024 : kThreads;
+  QrMap mp;
+  int ct = 1;
+  while (ct < b && ct < nt)
+    ct *= 2;
+  if (big && ct > 256)
+    ct = 256;  // two columns per thread beyond 256
+  mp.ct = ct;
+  static const long rows_target = [] {
+    const char* e = std::getenv("DLAF_MI355X_QR_ROWS");  // rows per workgroup of a large panel
+    return e ? std::max(16L, std::atol(e)) : 128L;
+  }();
+  long rows_per_wg = std::max<long>(rows_target, (m + max_wg - 1) / max_wg);
+  rows_per_wg = ((rows_per_wg + 15) / 16) * 16;
+  mp.rows_per_wg = (int) rows_per_wg;
+  mp.nwg = (int) ((m + rows_per_wg - 1) / rows_per_wg);
+  mp.spin_limit = qr_spin_limit();
+  // 16-byte reads of the partial-sum vectors: whole words per vector, a whole number of vectors per load round
+  const int W = (int) (vec_bytes / 16);
+  const int nrg = nt / ct;
+  mp.wide = (vec_bytes % 16 == 0 && W >= 1 && W <= nt && nt % W == 0 && nt / W <= std::max(nrg, 8) * (b > ct ? 1 : 1) &&
+             nt / W <= 16)
+                ? 1
+                : 0;
+  const int redrows = std::max(std::max(nrg, 8), mp.wide ? nt / W : 0);
+  const size_t lds = ((size_t) redrows * b + b + 4 + 4 * (size_t) rows_per_wg) * sizeof(T);
+  if (lds > 150 * 1024) {
+    fprintf(stderr, "[dlaf_mi355x] panel QR: %zu bytes of LDS for a %ld x %d panel\n", lds, m, b);
+    abort();
+  }
+  if (m * (long) b >= (1L << 31)) {
+    fprintf(stderr, "[dlaf_mi355x] panel QR: a %ld x %d panel exceeds the 32-bit element range of the kernel\n", m, b);
+    abort();
+  }
+  auto go = [&](auto cpt, auto ntag) {
+    constexpr int C = decltype(cpt)::value;
+    constexpr int N = decltype(ntag)::value;
+    hipLaunchKernelGGL((panel_qr_kernel<T, C, N>), dim3((unsigned) mp.nwg), dim3(N), lds, stream, qt, m, b, nr, taus, partial,
+                       counters, info, mp);
+  };
+  if (big) {
+    if (b <= ct)
+      go(std::integral_constant<int, 1>{}, std::integral_constant<int, 1024>{});
+    else
+      go(std::integral_constant<int, 2>{}, std::integral_constant<int, 1024>{});
+  }
+  else
+    go(std::integral_constant<int, 1>{}, std::integral_constant<int, kThreads>{});
 }
 
 template <class T>
@@ -788,7 +1001,9 @@ void launch_tfactor(const T* s, long lds_, const T* taus, int k, T* t, long ldt,
     fprintf(stderr, "[dlaf_mi355x] T factor: %d reflectors exceed the supported %d\n", k, kTfMax);
     abort();
   }
-  hipLaunchKernelGGL((tfactor_kernel<T>), dim3(1), dim3(kThreads), 0, stream, s, lds_, taus, k, t, ldt);
+  const int rows_per_wg = kThreads / 64;
+  hipLaunchKernelGGL((tfactor_kernel<T>), dim3((unsigned) ((k + rows_per_wg - 1) / rows_per_wg)), dim3(kThreads),
+                     (size_t) rows_per_wg * k * sizeof(T), stream, s, lds_, taus, k, t, ldt);
 }
 
 template <class T>
@@ -807,8 +1022,12 @@ static void band_init_one() {
                              Cfg::LDS_BYTES);
   (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_panel_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              Cfg::LDS_BYTES);
-  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&panel_qr_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             96 * 1024);
+  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&panel_qr_kernel<T, 1, kThreads>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&panel_qr_kernel<T, 1, 1024>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&panel_qr_kernel<T, 2, 1024>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
 }
 
 void band_kernels_init() {
