@@ -485,6 +485,13 @@ struct QrMap {
   int rows_per_wg;
   int ct;      // column threads (power of two)
   int wide;    // != 0: the partial-sum vectors are read in 16-byte words
+  // Hand-off buffers.  Nothing another workgroup reads is ever read twice from the same 128-byte line in one launch:
+  // the partial sums of step j live in slot j % nslots (nslots = the number of reflectors whenever that fits the
+  // scratch budget), the head row of step j in its own line-padded row of `heads` -- a line re-read after another
+  // XCD rewrote it may come out of the reader's L2 as it was (per-XCD L2s are not coherent; the acquire only drops L1).
+  int nslots;
+  long slot_elems;  // elements per slot (nwg vectors, padded to whole lines)
+  long head_elems;  // elements per head row (padded to whole lines)
   long spin_limit;
 };
 
@@ -521,7 +528,7 @@ __device__ __forceinline__ void qr_store_wt(T* p, const T& v) {
 //   version with a branch per row and 64-bit row arithmetic spent 12 of its 23 us per reflector issuing instructions.
 // Hand-offs: write-through stores + drained counter / relaxed poll + one acquire (the protocol of the tile POTRF).
 template <class T, int CPT, int NT>
-__global__ __launch_bounds__(NT) void panel_qr_kernel(T* qt, long m, int b, int nr, T* taus, T* partial,
+__global__ __launch_bounds__(NT) void panel_qr_kernel(T* qt, long m, int b, int nr, T* taus, T* partial, T* heads,
                                                             unsigned* counters, int* info, QrMap mp) {
   using R = real_t<T>;
   constexpr int kB = qr_batch<T, NT>();
@@ -582,12 +589,13 @@ __global__ __launch_bounds__(NT) void panel_qr_kernel(T* qt, long m, int b, int 
         return;
       }
       // ---- totals: every workgroup adds the shares in the same order, so all of them form the same reflector ----
-      const T* part = partial + (size_t) (j & 1) * mp.nwg * (size_t) b;
+      const T* part = partial + (size_t) (j % mp.nslots) * (size_t) mp.slot_elems;
+      const T* head = (j == 0) ? qt : heads + (size_t) j * (size_t) mp.head_elems;  // (row 0 comes from the caller)
       T hrow[CPT];
 #pragma unroll
       for (int u = 0; u < CPT; ++u) {
         const int c = tc + u * mp.ct;
-        hrow[u] = (rg == 0 && c < b && c >= j) ? qt[j * b + c] : zero_el<T>();
+        hrow[u] = (rg == 0 && c < b && c >= j) ? head[c] : zero_el<T>();
       }
       int G;  // partial-sum rows in `red`
       if (mp.wide) {
@@ -736,8 +744,10 @@ __global__ __launch_bounds__(NT) void panel_qr_kernel(T* qt, long m, int b, int 
         const int rrc = min(rr, rlast);
         const int r = first + rr;
         const bool rowact = rr < nrows;
-        const T vr = (r == j) ? make_el<T>(R(1), R(0)) : el_mul(xs[rrc], scale);
-        const T xn = el_sub(xo[rrc], el_mul(ctau, el_mul(vr, wn)));
+        // (opening pass: nothing is applied and xs holds nothing yet -- 0 * garbage must not reach the sums)
+        const T vr = !upd ? zero_el<T>() : (r == j) ? make_el<T>(R(1), R(0)) : el_mul(xs[rrc], scale);
+        const T xov = dots ? xo[rrc] : zero_el<T>();
+        const T xn = el_sub(xov, el_mul(ctau, el_mul(vr, wn)));
 #pragma unroll
         for (int u = 0; u < CPT; ++u) {
           const int c = tc + u * mp.ct;
@@ -761,8 +771,10 @@ __global__ __launch_bounds__(NT) void panel_qr_kernel(T* qt, long m, int b, int 
     if (head_hit && upd) {
 #pragma unroll
       for (int u = 0; u < CPT; ++u)
-        if (colact[u])
-          qr_store_wt(&qt[jn * b + tc + u * mp.ct], head_v[u]);
+        if (colact[u]) {
+          qt[jn * b + tc + u * mp.ct] = head_v[u];
+          qr_store_wt(&heads[(size_t) jn * (size_t) mp.head_elems + tc + u * mp.ct], head_v[u]);
+        }
     }
     QR_STAMP(4);
     // ---- publish my share of column j + 1 ---------------------------------------------------------------------------
@@ -774,7 +786,7 @@ __global__ __launch_bounds__(NT) void panel_qr_kernel(T* qt, long m, int b, int 
           red[(size_t) rg * b + c] = dnext[u];
       }
       __syncthreads();
-      T* mine = partial + ((size_t) (jn & 1) * mp.nwg + g) * (size_t) b;
+      T* mine = partial + (size_t) (jn % mp.nslots) * (size_t) mp.slot_elems + (size_t) g * (size_t) b;
       for (int c = threadIdx.x; c < b; c += NT) {
         T sum = red[c];
         for (int q = 1; q < nrg; ++q)
@@ -899,9 +911,19 @@ static long qr_spin_limit() {
   return v;
 }
 
+// scratch layout: [counters: b + 1 words, padded to 256 B | head rows: b line-padded rows | partial-sum slots]
+static size_t qr_line_pad(size_t bytes) {
+  return (bytes + 127) / 128 * 128;
+}
+static constexpr size_t kQrPartialBudget = 96u << 20;  // bytes of partial-sum slots
+static size_t qr_counter_bytes(int b) {
+  return (((size_t) (b + 1) * sizeof(unsigned)) + 255) / 256 * 256;
+}
 size_t panel_qr_scratch_bytes(int b, size_t elem_size) {
-  // partial sums [2][kQrMaxWg][b] + one counter per reflector
-  return 2 * (size_t) kQrMaxWg * (size_t) b * elem_size + (size_t) (b + 1) * sizeof(unsigned) + 64;
+  const size_t head = (size_t) b * qr_line_pad((size_t) b * elem_size);
+  const size_t one_slot = qr_line_pad((size_t) kQrMaxWg * (size_t) b * elem_size);
+  const size_t slots = std::max<size_t>(2, std::min<size_t>((size_t) b, kQrPartialBudget / one_slot));
+  return qr_counter_bytes(b) + head + slots * one_slot + 256;
 }
 
 template <class T>
@@ -912,9 +934,11 @@ void launch_panel_qr(T* qt, long m, int b, int nr, T* taus, void* scratch, int* 
     fprintf(stderr, "[dlaf_mi355x] panel QR: band size %d exceeds the supported %d\n", b, kQrMaxColsPerThread * kThreads);
     abort();
   }
-  T* partial = static_cast<T*>(scratch);
-  unsigned* counters = reinterpret_cast<unsigned*>(static_cast<char*>(scratch) + 2 * (size_t) kQrMaxWg * (size_t) b * sizeof(T));
-  (void) hipMemsetAsync(counters, 0, (size_t) (b + 1) * sizeof(unsigned), stream);
+  unsigned* counters = static_cast<unsigned*>(scratch);
+  T* heads = reinterpret_cast<T*>(static_cast<char*>(scratch) + qr_counter_bytes(b));
+  const size_t head_bytes = qr_line_pad((size_t) b * sizeof(T));
+  T* partial = reinterpret_cast<T*>(reinterpret_cast<char*>(heads) + (size_t) b * head_bytes);
+  (void) hipMemsetAsync(counters, 0, qr_counter_bytes(b), stream);
   const size_t vec_bytes = (size_t) b * sizeof(T);
   static const int max_wg = [] {
     const char* e = std::getenv("DLAF_MI355X_QR_MAXWG");  // tuning / debugging: 1 = the whole panel in one workgroup
@@ -941,6 +965,14 @@ void launch_panel_qr(T* qt, long m, int b, int nr, T* taus, void* scratch, int* 
   mp.rows_per_wg = (int) rows_per_wg;
   mp.nwg = (int) ((m + rows_per_wg - 1) / rows_per_wg);
   mp.spin_limit = qr_spin_limit();
+  {
+    const size_t slot_bytes = qr_line_pad((size_t) mp.nwg * vec_bytes);
+    const size_t one_slot_max = qr_line_pad((size_t) kQrMaxWg * vec_bytes);
+    const size_t slots_cap = std::max<size_t>(2, std::min<size_t>((size_t) b, kQrPartialBudget / one_slot_max));
+    mp.nslots = (int) std::min<size_t>((size_t) std::max(nr, 2), std::max<size_t>(2, slots_cap * one_slot_max / slot_bytes));
+    mp.slot_elems = (long) (slot_bytes / sizeof(T));
+    mp.head_elems = (long) (head_bytes / sizeof(T));
+  }
   // 16-byte reads of the partial-sum vectors: whole words per vector, a whole number of vectors per load round
   const int W = (int) (vec_bytes / 16);
   const int nrg = nt / ct;
@@ -962,7 +994,7 @@ void launch_panel_qr(T* qt, long m, int b, int nr, T* taus, void* scratch, int* 
     constexpr int C = decltype(cpt)::value;
     constexpr int N = decltype(ntag)::value;
     hipLaunchKernelGGL((panel_qr_kernel<T, C, N>), dim3((unsigned) mp.nwg), dim3(N), lds, stream, qt, m, b, nr, taus, partial,
-                       counters, info, mp);
+                       heads, counters, info, mp);
   };
   if (big) {
     if (b <= ct)

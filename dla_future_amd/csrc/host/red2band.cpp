@@ -26,6 +26,7 @@
 //     cooperative kernel (panel_qr_kernel) instead of a per-reflector reduction over the column communicator.
 // One stream, no lookahead yet (DESIGN.md says what that costs).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -97,16 +98,20 @@ int reduction_to_band_device(DeviceMatrix<T>& A, int band, T* taus_host) {
 
   // ---- workspaces --------------------------------------------------------------------------------------------
   T* qt = dalloc<T>((size_t) b * (size_t) n);
-  T* V = dalloc<T>((size_t) ldp * b);
+  // V and X alternate between two buffers: the bulk of the trailing update of panel p reads them on the second
+  // stream while the panel chain of p + 1 is already writing the next ones
+  T* Vb[2] = {dalloc<T>((size_t) ldp * b), dalloc<T>((size_t) ldp * b)};
   T* W = dalloc<T>((size_t) ldp * b);
-  T* X = dalloc<T>((size_t) ldp * b);
+  T* Xb[2] = {dalloc<T>((size_t) ldp * b), dalloc<T>((size_t) ldp * b)};
   T* S = dalloc<T>((size_t) b * b);
   T* Tm = dalloc<T>((size_t) b * b);
   T* W2 = dalloc<T>((size_t) b * b);
   T* taus = dalloc<T>((size_t) nrefls + 1);
-  DLAF_HIP_CHECK(hipMemsetAsync(V, 0, (size_t) ldp * b * sizeof(T), s));
+  for (int q = 0; q < 2; ++q) {
+    DLAF_HIP_CHECK(hipMemsetAsync(Vb[q], 0, (size_t) ldp * b * sizeof(T), s));
+    DLAF_HIP_CHECK(hipMemsetAsync(Xb[q], 0, (size_t) ldp * b * sizeof(T), s));
+  }
   DLAF_HIP_CHECK(hipMemsetAsync(W, 0, (size_t) ldp * b * sizeof(T), s));
-  DLAF_HIP_CHECK(hipMemsetAsync(X, 0, (size_t) ldp * b * sizeof(T), s));
   DLAF_HIP_CHECK(hipMemsetAsync(taus, 0, ((size_t) nrefls + 1) * sizeof(T), s));
   const int ksplit_max = std::max(1, gemm_pick_ksplit<T>(b, b, n));
   T* gpart = dalloc<T>(gemm_partial_elems<T>(b, b, ksplit_max));
@@ -125,11 +130,32 @@ int reduction_to_band_device(DeviceMatrix<T>& A, int band, T* taus_host) {
   DLAF_HIP_CHECK(hipEventCreate(&ev0));
   DLAF_HIP_CHECK(hipEventCreate(&ev1));
   DLAF_HIP_CHECK(hipEventRecord(ev0, s));
+  // Lookahead (one process): the trailing update of panel p is issued in two launches -- the tile column that
+  // holds panel p + 1 on the panel stream, everything else on a second stream -- so that the latency-bound panel
+  // kernel of p + 1 runs beside the bulk of the update of p; X = A W of p + 1 waits for both.
+  // DLAF_MI355X_R2B_LOOKAHEAD=1 turns it on (off by default, see below).
+  static const bool want_lookahead = [] {
+    const char* e = std::getenv("DLAF_MI355X_R2B_LOOKAHEAD");
+    return e ? std::atoi(e) != 0 : false;  // measured: no gain (the panel kernel's 1024-thread workgroups need whole CUs)
+  }();
+  const bool lookahead = want_lookahead && !dist && A.s_low != A.s_high;
+  hipStream_t s2 = lookahead ? A.s_low : s;
+  hipEvent_t ev_x[2], ev_rest[2];
+  for (int q = 0; q < 2; ++q) {
+    DLAF_HIP_CHECK(hipEventCreateWithFlags(&ev_x[q], hipEventDisableTiming));
+    DLAF_HIP_CHECK(hipEventCreateWithFlags(&ev_rest[q], hipEventDisableTiming));
+  }
+  if (lookahead) {
+    DLAF_HIP_CHECK(hipEventRecord(ev_x[0], s));
+    DLAF_HIP_CHECK(hipStreamWaitEvent(s2, ev_x[0], 0));  // the workspaces are ready
+  }
 
   const CommAxis ax_row = CommAxis::Row, ax_col = CommAxis::Col;
   for (long p = 0; p < npanels; ++p) {
     if (tr)
       tr->mark(p);
+    T* V = Vb[p & 1];
+    T* X = Xb[p & 1];
     const long r0 = (p + 1) * b, c0 = p * b;
     const int nr = (int) std::min<long>(b, nrefls - c0);
     if (nr <= 0)
@@ -229,6 +255,8 @@ int reduction_to_band_device(DeviceMatrix<T>& A, int band, T* taus_host) {
     h.layers_t = tile_panel_pick_layers(ltc - jl0, nb, b, std::max<long>(ltr - il0, 1), sizeof(T));
     h.part_s = part_s;
     h.part_t = part_t;
+    if (lookahead && p > 0)
+      DLAF_HIP_CHECK(hipStreamWaitEvent(s, ev_rest[(p - 1) & 1], 0));  // the bulk of the previous trailing update
     launch_tile_panel(h, s);
     launch_hemm_reduce(h, r0, X, ldp, s);
     if (dist)
@@ -271,7 +299,9 @@ int reduction_to_band_device(DeviceMatrix<T>& A, int band, T* taus_host) {
       launch_gemm(g, s);
     }
     // ---- 6. A_t -= X V^H + V X^H on the lower tiles (tile::her2k / 2 x tile::gemm, impl.h:545-585) ----------------
-    if (il0 < ltr && jl0 < ltc) {
+    auto her2k = [&](long ja, long jb, hipStream_t st) {
+      if (il0 >= ltr || ja >= jb)
+        return;
       UpdateArgs<T> ua;
       ua.c = A.tiles;
       ua.c_tsr = (long) te;
@@ -281,14 +311,14 @@ int reduction_to_band_device(DeviceMatrix<T>& A, int band, T* taus_host) {
       ua.a2 = V + (rows.global_of(il0) * nb - e0);
       ua.a_ts = (long) rows.P * nb;
       ua.lda = (int) ldp;
-      ua.b = V + (cols.global_of(jl0) * nb - e0);
-      ua.b2 = X + (cols.global_of(jl0) * nb - e0);
+      ua.b = V + (cols.global_of(ja) * nb - e0);
+      ua.b2 = X + (cols.global_of(ja) * nb - e0);
       ua.b_ts = (long) cols.P * nb;
       ua.ldb = (int) ldp;
       ua.il0 = (int) il0;
       ua.il1 = (int) ltr;
-      ua.jl0 = (int) jl0;
-      ua.jl1 = (int) ltc;
+      ua.jl0 = (int) ja;
+      ua.jl1 = (int) jb;
       ua.nb = nb;
       ua.K1 = b;
       ua.K = 2 * b;
@@ -300,10 +330,25 @@ int reduction_to_band_device(DeviceMatrix<T>& A, int band, T* taus_host) {
       ua.nt = (int) nt;
       ua.last_rows = rows.last_extent();
       ua.info = info;
-      launch_update(ua, s, 3);
+      launch_update(ua, st, 3);
+    };
+    if (lookahead) {
+      // the tile column of the next panel first, on the panel stream; the rest beside the next panel chain
+      const long jsplit = std::min<long>(ltc, jl0 + 1);
+      DLAF_HIP_CHECK(hipEventRecord(ev_x[p & 1], s));
+      her2k(jl0, jsplit, s);
+      DLAF_HIP_CHECK(hipStreamWaitEvent(s2, ev_x[p & 1], 0));
+      her2k(jsplit, ltc, s2);
+      DLAF_HIP_CHECK(hipEventRecord(ev_rest[p & 1], s2));
     }
+    else
+      her2k(jl0, ltc, s);
     if (dist)
       DLAF_HIP_CHECK(hipStreamSynchronize(s));
+  }
+  if (lookahead) {
+    DLAF_HIP_CHECK(hipEventRecord(ev_rest[0], s2));
+    DLAF_HIP_CHECK(hipStreamWaitEvent(s, ev_rest[0], 0));
   }
   DLAF_HIP_CHECK(hipEventRecord(ev1, s));
   int h_info = 0;
@@ -317,7 +362,11 @@ int reduction_to_band_device(DeviceMatrix<T>& A, int band, T* taus_host) {
   g_last_flops = (TypeInfo<T>::is_complex ? 4.0 : 1.0) * 4.0 / 3.0 * (double) n * (double) n * (double) n;
   DLAF_HIP_CHECK(hipEventDestroy(ev0));
   DLAF_HIP_CHECK(hipEventDestroy(ev1));
-  for (T* q : {qt, V, W, X, S, Tm, W2, taus, gpart, part_s, part_t})
+  for (int q = 0; q < 2; ++q) {
+    DLAF_HIP_CHECK(hipEventDestroy(ev_x[q]));
+    DLAF_HIP_CHECK(hipEventDestroy(ev_rest[q]));
+  }
+  for (T* q : {qt, Vb[0], Vb[1], W, Xb[0], Xb[1], S, Tm, W2, taus, gpart, part_s, part_t})
     DLAF_HIP_CHECK(hipFree(q));
   DLAF_HIP_CHECK(hipFree(qr_scratch));
   if (h_info == kInfoSchedulingFailure)
