@@ -51,8 +51,10 @@ int gemm_pick_ksplit(int M, int N, long K);
 // herm != 0 (xHEMM with a lower-stored Hermitian matrix, reduction_to_band/impl.h:465-517): kind S takes the
 // tiles gi >= gj (the diagonal tile through its Hermitian image), kind T the tiles gi > gj.  herm == 0: every
 // tile of the local range (bt_reduction_to_band's W2 = W^H C runs as kind T on the tiles of C).
-// The sources of an output tile are dealt out to `layers_*` layers (source index mod layers), one workgroup per
-// (output block, layer); every layer is a column-major panel part_*[layer]: (out tiles * nb) x ncols.
+// The sources of an output tile are cut into runs of `chunk_*` consecutive tiles, one workgroup per (output block,
+// run): equal work per workgroup although the output tiles of a triangle have 1 .. nt sources.  Run q of an output
+// tile writes layer q, a column-major panel part_*[q]: (out tiles * nb) x ncols; a tile with fewer runs leaves the
+// higher layers alone and the reduction knows (tile_panel_runs).
 // W: row of global element g at w[(g - e0) + c * ldw].
 template <class T>
 struct TilePanelArgs {
@@ -69,12 +71,16 @@ struct TilePanelArgs {
   long e0 = 0;
   int ncols = 0;
   int kinds = 3;  // bit 0: S, bit 1: T
-  int layers_s = 1, layers_t = 1;
-  T* part_s = nullptr;  // layers_s panels of (il1 - il0) * nb rows
-  T* part_t = nullptr;  // layers_t panels of (jl1 - jl0) * nb rows
+  int chunk_s = 1, chunk_t = 1;    // source tiles per run
+  int layers_s = 1, layers_t = 1;  // most runs an output tile can have = layers allocated (tile_panel_layers)
+  T* part_s = nullptr;  // layers_s (+ 1, see `split`) panels of (il1 - il0) * nb rows
+  T* part_t = nullptr;  // layers_t (+ 1) panels of (jl1 - jl0) * nb rows
+  // set by launch_tile_panel: != 0 when the full off-diagonal tiles went through the fixed-mode kernels and the rest
+  // (diagonal tiles, ragged last tile row / column) through the general one into ONE EXTRA layer per kind
+  int split = 0;
 };
 template <class T>
-void launch_tile_panel(const TilePanelArgs<T>& args, hipStream_t stream);
+void launch_tile_panel(TilePanelArgs<T>& args, hipStream_t stream);
 // Hermitian case: x[(g - e0) + c * ldx] for the global rows g of the tiles I0 .. nt-1 = the layer sums of the
 // kinds whose output tile is local (zero otherwise; rows g < r0 are set to zero)
 template <class T>
@@ -82,8 +88,12 @@ void launch_hemm_reduce(const TilePanelArgs<T>& args, long r0, T* x, long ldx, h
 // kind T alone (herm == 0): out[(jl - jl0) * nb + r + c * ldo] = sum over the layers
 template <class T>
 void launch_layers_reduce(const T* part, int layers, long rows, int ncols, T* out, long ldo, hipStream_t stream);
-// layers for `out_tiles` output tiles of `sub` row blocks each (enough work items to fill the GPU, at most `max_src`)
-int tile_panel_pick_layers(long out_tiles, int nb, int ncols, long max_src, size_t elem_size);
+// source tiles per run for `out_tiles` output tiles with up to `max_src` sources each (about a thousand workgroups
+// per kind), and the layers that needs: ceil(max_src / chunk)
+int tile_panel_pick_chunk(long out_tiles, int nb, int ncols, long max_src, bool triangle, size_t elem_size);
+inline int tile_panel_layers(long max_src, int chunk) {
+  return (int) ((max_src + chunk - 1) / chunk > 0 ? (max_src + chunk - 1) / chunk : 1);
+}
 
 // ------------------------------------------------------------------------------------------
 // Panel of Householder reflectors (xGEQR2 of an m x b panel, reflectors of size 1 skipped; the reference's

@@ -127,8 +127,51 @@ struct OpSlab {
     }
   }
 
+  // Transposed image (TIMG, mode 1 operands of the fixed-mode kernels): [row][LDT = BK + 2] instead of [k][LD].
+  // Stored as loaded -- VE consecutive k of one row, one 16-byte LDS write for real types -- and read by the MFMA
+  // fragments with a row stride of LDT words: (c LDT + g) mod 32 is distinct over the 32 lanes of a read group
+  // (LDT = 18: even multiples of 18 hit the even banks once, the neighbour k the odd ones), so neither side
+  // conflicts.  In the [k][LD] image the same store is 8-way conflicted (LD = 0 mod 16 words puts the eight k
+  // pairs of a row on one bank): measured, it kept both xHEMM kernels at 33 TFlop/s.
+  static constexpr int LDT = BK + 2;
+  static constexpr bool TIMG_FITS = ROWS * LDT <= PLANE;
+  template <bool TIMG>
   __device__ __forceinline__ void store(R* __restrict__ lds, int mode, bool cj) const {
     const int t = threadIdx.x;
+    if constexpr (TIMG) {
+      static_assert(TIMG_FITS, "transposed image must fit the slab plane");
+      // (mode 1 only: the caller promised it)
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const int idx = t + THREADS * q;
+        const int k = (idx % (BK / VE)) * VE;
+        const int r = idx / (BK / VE);
+        R* d = lds + r * LDT + k;
+        if constexpr (!CX) {
+          if constexpr (VE * sizeof(R) == 16 && (LDT * sizeof(R)) % 16 == 0) {
+            typedef R rv __attribute__((ext_vector_type(VE)));
+            rv v;
+#pragma unroll
+            for (int e = 0; e < VE; ++e)
+              v[e] = regs[q * VE + e];
+            *reinterpret_cast<rv*>(d) = v;
+          }
+          else {
+#pragma unroll
+            for (int e = 0; e < VE; ++e)
+              d[e] = regs[q * VE + e];
+          }
+        }
+        else {
+#pragma unroll
+          for (int e = 0; e < VE; ++e) {
+            d[e] = re_of(regs[q * VE + e]);
+            d[PLANE + e] = cj ? -im_of(regs[q * VE + e]) : im_of(regs[q * VE + e]);
+          }
+        }
+      }
+      return;
+    }
     auto put = [&](int r, int k, const T& v) {
       lds[k * LD + r] = re_of(v);
       if constexpr (CX)
@@ -166,9 +209,52 @@ struct OpSlab {
   }
 };
 
+// one BK slab of MFMAs like mma_slab (mma_core.hpp), each operand image either [k][LD] or transposed [row][BK + 2]
+template <class Cfg, bool TA, bool TB>
+__device__ __forceinline__ void mma_slab_g(const typename Cfg::R* __restrict__ As, const typename Cfg::R* __restrict__ Bs,
+                                           Acc<Cfg>& acc, int wm, int wn, int lane) {
+  using R = typename Cfg::R;
+  constexpr int LDT = Cfg::BK + 2;
+  const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+  for (int k4 = 0; k4 < Cfg::BK / 4; ++k4) {
+    const int kk = k4 * 4 + g;
+    R a_re[Cfg::TM], a_im[Cfg::TM], b_re[Cfg::TN], b_im[Cfg::TN];
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i) {
+      const int row = wm * Cfg::WM + i * 16 + c;
+      const int off = TA ? row * LDT + kk : kk * Cfg::LDA + row;
+      a_re[i] = As[off];
+      if constexpr (Cfg::CX)
+        a_im[i] = As[Cfg::A_PLANE + off];
+    }
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+      const int row = wn * Cfg::WN + j * 16 + c;
+      const int off = TB ? row * LDT + kk : kk * Cfg::LDB + row;
+      b_re[j] = Bs[off];
+      if constexpr (Cfg::CX)
+        b_im[j] = Bs[Cfg::B_PLANE + off];
+    }
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+      for (int i = 0; i < Cfg::TM; ++i) {
+        acc.re[i][j] = Mma<R>::mma(b_re[j], a_re[i], acc.re[i][j]);
+        if constexpr (Cfg::CX) {
+          acc.re[i][j] = Mma<R>::mma(b_im[j], a_im[i], acc.re[i][j]);
+          acc.im[i][j] = Mma<R>::mma(b_re[j], a_im[i], acc.im[i][j]);
+          acc.im[i][j] = Mma<R>::mma_neg(b_im[j], a_re[i], acc.im[i][j]);
+        }
+      }
+  }
+}
+
 // acc += a(mrows x K) * b(ncols x K)^H  (rows >= mrows / ncols and k >= K contribute zero).  All threads of the
 // workgroup call it; lds: 2 * Cfg::BUF_ELEMS of R (Cfg must be an un-paired, plane-separated configuration).
-template <class Cfg, class T>
+// MA / MB >= 0: the slab mode of the operand is a compile-time promise of the caller (the loaders of the other modes are
+// not even compiled into the kernel: a kernel that may meet every mode keeps the registers of all three loaders busy)
+template <class Cfg, class T, int MA = -1, int MB = -1>
 __device__ __forceinline__ void gemm_acc(const OpDesc<T>& da, int mrows, const OpDesc<T>& db, int ncols, int K,
                                          typename Cfg::R* __restrict__ lds, Acc<Cfg>& acc) {
   using R = typename Cfg::R;
@@ -179,13 +265,17 @@ __device__ __forceinline__ void gemm_acc(const OpDesc<T>& da, int mrows, const O
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int wm = wave % Cfg::WAVES_M, wn = wave / Cfg::WAVES_M;
-  OpSlab<T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS> sa;
-  OpSlab<T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS> sb;
-  const int ma = sa.pick_mode(da, mrows, K), mb = sb.pick_mode(db, ncols, K);
+  using SA = OpSlab<T, Cfg::BM, Cfg::BK, Cfg::LDA, Cfg::THREADS>;
+  using SB = OpSlab<T, Cfg::BN, Cfg::BK, Cfg::LDB, Cfg::THREADS>;
+  SA sa;
+  SB sb;
+  // fixed k-contiguous operands go through the transposed LDS image (OpSlab::store)
+  constexpr bool TA = MA == 1 && SA::TIMG_FITS, TB = MB == 1 && SB::TIMG_FITS;
+  const int ma = MA >= 0 ? MA : sa.pick_mode(da, mrows, K), mb = MB >= 0 ? MB : sb.pick_mode(db, ncols, K);
   sa.load(da, ma, 0, mrows, K);
   sb.load(db, mb, 0, ncols, K);
-  sa.store(lds, ma, da.conj != 0);
-  sb.store(lds + Cfg::A_ELEMS, mb, db.conj != 0);
+  sa.template store<TA>(lds, ma, da.conj != 0);
+  sb.template store<TB>(lds + Cfg::A_ELEMS, mb, db.conj != 0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     R* cur = lds + (kt & 1) * Cfg::BUF_ELEMS;
@@ -195,10 +285,13 @@ __device__ __forceinline__ void gemm_acc(const OpDesc<T>& da, int mrows, const O
       sa.load(da, ma, (kt + 1) * Cfg::BK, mrows, K);
       sb.load(db, mb, (kt + 1) * Cfg::BK, ncols, K);
     }
-    mma_slab<Cfg>(cur, cur + Cfg::A_ELEMS, acc, wm, wn, lane);
+    if constexpr (TA || TB)
+      mma_slab_g<Cfg, TA, TB>(cur, cur + Cfg::A_ELEMS, acc, wm, wn, lane);
+    else
+      mma_slab<Cfg>(cur, cur + Cfg::A_ELEMS, acc, wm, wn, lane);
     if (more) {
-      sa.store(nxt, ma, da.conj != 0);
-      sb.store(nxt + Cfg::A_ELEMS, mb, db.conj != 0);
+      sa.template store<TA>(nxt, ma, da.conj != 0);
+      sb.template store<TB>(nxt + Cfg::A_ELEMS, mb, db.conj != 0);
     }
     __syncthreads();
   }

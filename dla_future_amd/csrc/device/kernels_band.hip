@@ -183,17 +183,47 @@ struct TilePanelMap {
   int cbn;     // BN-column blocks of the panel
   long cnt_s;  // work items of kind S (they come first)
   long cnt_t;
+  int chunk_s, chunk_t;    // source tiles per run (one run = one workgroup)
+  int layers_s, layers_t;  // runs enumerated per output tile
+  int base_s, base_t;      // first layer it writes
+  int only_special;        // KIND 2: take only the sources the fixed-mode kernels leave out
 };
 
+// sources of output tile t: local tile columns [first, end) of tile row il0 + t (kind S) / local tile rows [first, end)
+// of tile column jl0 + t (kind T); go = the output tile's global index
 template <class T>
-__global__ __launch_bounds__(GenCfg<T>::type::THREADS, 1) void tile_panel_kernel(TilePanelArgs<T> p, TilePanelMap mp) {
+__device__ __forceinline__ void tile_panel_sources(const TilePanelArgs<T>& p, bool kind_t, int t, int& first, int& end) {
+  if (!kind_t) {
+    const int gi = (p.il0 + t) * p.pr + p.ri;
+    first = p.jl0;
+    end = p.jl1;
+    if (p.herm)  // tiles on and left of the diagonal: gj = jl pc + ci <= gi
+      end = gi >= p.ci ? min(p.jl1, (gi - p.ci) / p.pc + 1) : p.jl0;
+  }
+  else {
+    const int gj = (p.jl0 + t) * p.pc + p.ci;
+    first = p.il0;
+    end = p.il1;
+    if (p.herm && gj >= p.ri)  // tiles below the diagonal: gi = il pr + ri > gj
+      first = max(p.il0, (gj - p.ri) / p.pr + 1);
+  }
+  if (end < first)
+    end = first;
+}
+
+// KIND 0: kind S over the full off-diagonal tiles (A rows contiguous, W k-contiguous: slab modes 0 / 1 fixed)
+// KIND 1: kind T over the full tiles (A k-contiguous, conjugated: modes 1 / 1 fixed)
+// KIND 2: both kinds, any tile (run-time slab modes: Hermitian diagonal tiles, ragged extents, unaligned operands)
+template <class T, int KIND>
+__global__ __launch_bounds__(GenCfg<T>::type::THREADS, KIND == 2 ? 1 : 2) void tile_panel_kernel(TilePanelArgs<T> p,
+                                                                                                   TilePanelMap mp) {
   using Cfg = typename GenCfg<T>::type;
   using R = real_t<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   R* lds = reinterpret_cast<R*>(lds_raw);
   long id = blockIdx.x;
-  const bool kind_t = id >= mp.cnt_s;
-  if (kind_t)
+  const bool kind_t = KIND == 1 || (KIND == 2 && id >= mp.cnt_s);
+  if (KIND == 2 && kind_t)
     id -= mp.cnt_s;
   const int cb = (int) (id % mp.cbn);
   id /= mp.cbn;
@@ -202,62 +232,84 @@ __global__ __launch_bounds__(GenCfg<T>::type::THREADS, 1) void tile_panel_kernel
   const int ot = kind_t ? (p.jl1 - p.jl0) : (p.il1 - p.il0);
   const int t = (int) (id % ot);
   const int q = (int) (id / ot);
-  const int layers = kind_t ? p.layers_t : p.layers_s;
+  const int chunk = kind_t ? mp.chunk_t : mp.chunk_s;
   const long te = (long) p.nb * p.nb;
   const int n0 = cb * Cfg::BN;
   const int ncols = min(Cfg::BN, p.ncols - n0);
   Acc<Cfg> acc;
   acc.clear();
-  // the output tile: local tile row il (kind S) / local tile column jl (kind T); its sources: the tiles of that
-  // tile row left of (and on) the diagonal / of that tile column below the diagonal, dealt out to the layers
+  // the output tile: local tile row il (kind S) / local tile column jl (kind T); run q of its sources
   const int go = kind_t ? (p.jl0 + t) * p.pc + p.ci : (p.il0 + t) * p.pr + p.ri;
   const int ext_o = kind_t ? ((go == p.nt_c - 1) ? p.last_cols : p.nb) : ((go == p.nt_r - 1) ? p.last_rows : p.nb);
   const int mrows = min(Cfg::BM, ext_o - s * Cfg::BM);
-  if (mrows > 0) {
-    int first = kind_t ? p.il0 : p.jl0;
-    const int end = kind_t ? p.il1 : p.jl1;
-    if (kind_t && p.herm && go >= p.ri)
-      first = max(p.il0, (go - p.ri) / p.pr + 1);
-    for (int src = first + q; src < end; src += layers) {
+  int first, end;
+  tile_panel_sources(p, kind_t, t, first, end);
+  if (mp.only_special == 0 || KIND != 2) {
+    // (the general kernel in split mode keeps one run: all the special sources of an output tile)
+    first += q * chunk;
+    end = min(end, first + chunk);
+  }
+  if (mrows <= 0 || first >= end)
+    return;  // no such run: the reduction does not read this layer of this tile
+  {
+    for (int src = first; src < end; ++src) {
       const int il = kind_t ? src : p.il0 + t;
       const int jl = kind_t ? p.jl0 + t : src;
       const int gi = il * p.pr + p.ri, gj = jl * p.pc + p.ci;
-      if (!kind_t && p.herm && gj > gi)
-        break;
       // the tile the panel rows come from: global tile column gj (kind S) / global tile row gi (kind T)
       const int gk = kind_t ? gi : gj;
       const int kext = kind_t ? ((gi == p.nt_r - 1) ? p.last_rows : p.nb) : ((gj == p.nt_c - 1) ? p.last_cols : p.nb);
+      // "special" sources: what the fixed-mode kernels cannot take
+      const bool special = (p.herm && gi == gj) || kext != p.nb || ext_o != p.nb;
+      if (KIND != 2 && special)
+        continue;
+      if (KIND == 2 && mp.only_special && !special)
+        continue;
       const T* tile = p.tiles + ((long) il + (long) jl * p.ltr) * te;
       OpDesc<T> da, db;
-      if (kind_t) {
-        da.p = tile + (long) (s * Cfg::BM) * p.nb;
-        da.rs = p.nb;
-        da.ks = 1;
-        da.conj = 1;
-      }
-      else if (p.herm && gj == gi) {
-        da.p = tile;
-        da.rs = 1;
-        da.ks = p.nb;
-        da.herm = 1;
-        da.roff = s * Cfg::BM;
-      }
-      else {
-        da.p = tile + s * Cfg::BM;
-        da.rs = 1;
-        da.ks = p.nb;
-      }
       db.p = p.w + ((long) gk * p.nb - p.e0) + (long) n0 * p.ldw;
       db.rs = p.ldw;
       db.ks = 1;
       db.conj = 1;
-      gemm_acc<Cfg, T>(da, mrows, db, ncols, kext, lds, acc);
+      if constexpr (KIND == 0) {
+        da.p = tile + s * Cfg::BM;
+        da.rs = 1;
+        da.ks = p.nb;
+        gemm_acc<Cfg, T, 0, 1>(da, mrows, db, ncols, kext, lds, acc);
+      }
+      else if constexpr (KIND == 1) {
+        da.p = tile + (long) (s * Cfg::BM) * p.nb;
+        da.rs = p.nb;
+        da.ks = 1;
+        da.conj = 1;
+        gemm_acc<Cfg, T, 1, 1>(da, mrows, db, ncols, kext, lds, acc);
+      }
+      else {
+        if (kind_t) {
+          da.p = tile + (long) (s * Cfg::BM) * p.nb;
+          da.rs = p.nb;
+          da.ks = 1;
+          da.conj = 1;
+        }
+        else if (p.herm && gj == gi) {
+          da.p = tile;
+          da.rs = 1;
+          da.ks = p.nb;
+          da.herm = 1;
+          da.roff = s * Cfg::BM;
+        }
+        else {
+          da.p = tile + s * Cfg::BM;
+          da.rs = 1;
+          da.ks = p.nb;
+        }
+        gemm_acc<Cfg, T>(da, mrows, db, ncols, kext, lds, acc);
+      }
     }
   }
-  if (mrows <= 0)
-    return;
   const long ldp = (long) ot * p.nb;
-  T* part = (kind_t ? p.part_t : p.part_s) + (size_t) q * (size_t) p.ncols * (size_t) ldp + (long) t * p.nb + s * Cfg::BM;
+  const int layer = q + (kind_t ? mp.base_t : mp.base_s);
+  T* part = (kind_t ? p.part_t : p.part_s) + (size_t) layer * (size_t) p.ncols * (size_t) ldp + (long) t * p.nb + s * Cfg::BM;
   acc_foreach<Cfg, T>(acc, [&](int m, int n, const T& v) {
     if (m < mrows && n < ncols)
       part[m + (long) (n0 + n) * ldp] = v;
@@ -278,15 +330,31 @@ __global__ __launch_bounds__(kThreads) void hemm_reduce_kernel(TilePanelArgs<T> 
       const int gt = (int) (g / p.nb), r = (int) (g % p.nb);
       if ((p.kinds & 1) && gt >= p.ri && (gt - p.ri) % p.pr == 0) {
         const int il = (gt - p.ri) / p.pr;
-        if (il >= p.il0 && il < p.il1)
-          for (int q = 0; q < p.layers_s; ++q)
-            v = el_add(v, p.part_s[((size_t) q * p.ncols + c) * (size_t) lds_ + (long) (il - p.il0) * p.nb + r]);
+        if (il >= p.il0 && il < p.il1) {
+          int first, end;
+          tile_panel_sources(p, false, il - p.il0, first, end);
+          if (end > first) {
+            const int runs = (end - first + p.chunk_s - 1) / p.chunk_s;
+            for (int q = 0; q < runs; ++q)
+              v = el_add(v, p.part_s[((size_t) q * p.ncols + c) * (size_t) lds_ + (long) (il - p.il0) * p.nb + r]);
+            if (p.split)
+              v = el_add(v, p.part_s[((size_t) p.layers_s * p.ncols + c) * (size_t) lds_ + (long) (il - p.il0) * p.nb + r]);
+          }
+        }
       }
       if ((p.kinds & 2) && gt >= p.ci && (gt - p.ci) % p.pc == 0) {
         const int jl = (gt - p.ci) / p.pc;
-        if (jl >= p.jl0 && jl < p.jl1)
-          for (int q = 0; q < p.layers_t; ++q)
-            v = el_add(v, p.part_t[((size_t) q * p.ncols + c) * (size_t) ldt + (long) (jl - p.jl0) * p.nb + r]);
+        if (jl >= p.jl0 && jl < p.jl1) {
+          int first, end;
+          tile_panel_sources(p, true, jl - p.jl0, first, end);
+          if (end > first) {
+            const int runs = (end - first + p.chunk_t - 1) / p.chunk_t;
+            for (int q = 0; q < runs; ++q)
+              v = el_add(v, p.part_t[((size_t) q * p.ncols + c) * (size_t) ldt + (long) (jl - p.jl0) * p.nb + r]);
+            if (p.split)
+              v = el_add(v, p.part_t[((size_t) p.layers_t * p.ncols + c) * (size_t) ldt + (long) (jl - p.jl0) * p.nb + r]);
+          }
+        }
       }
     }
     x[row + (long) c * ldx] = v;
@@ -858,29 +926,81 @@ void launch_gemm(const GemmArgs<T>& a, hipStream_t stream) {
                        dim3(kThreads), 0, stream, a, mp);
 }
 
-int tile_panel_pick_layers(long out_tiles, int nb, int ncols, long max_src, size_t elem_size) {
+int tile_panel_pick_chunk(long out_tiles, int nb, int ncols, long max_src, bool triangle, size_t elem_size) {
   if (out_tiles <= 0 || max_src <= 1)
     return 1;
   const int bm = 128, bn = elem_size == 16 ? 64 : 128;
-  const long per_layer = out_tiles * ((nb + bm - 1) / bm) * ((ncols + bn - 1) / bn);
-  long layers = (768 + per_layer - 1) / per_layer;
-  layers = std::max<long>(1, std::min<long>(layers, max_src));
-  return (int) std::min<long>(layers, 64);
+  const long blocks = out_tiles * ((nb + bm - 1) / bm) * ((ncols + bn - 1) / bn);
+  // source tiles in all: a triangle has about half of out_tiles x max_src
+  const long tiles = blocks * max_src / (triangle ? 2 : 1);
+  static const long target = [] {
+    const char* e = std::getenv("DLAF_MI355X_TILE_PANEL_ITEMS");  // workgroups per kind to aim at
+    return e ? std::max(1L, std::atol(e)) : 1024L;
+  }();
+  long chunk = (tiles + target - 1) / target;
+  chunk = std::max<long>(1, std::min<long>(chunk, max_src));
+  // at most 64 layers
+  chunk = std::max<long>(chunk, (max_src + 63) / 64);
+  return (int) chunk;
 }
 
 template <class T>
-void launch_tile_panel(const TilePanelArgs<T>& a, hipStream_t stream) {
+void launch_tile_panel(TilePanelArgs<T>& a, hipStream_t stream) {
   using Cfg = typename GenCfg<T>::type;
+  a.split = 0;
   if (a.il1 <= a.il0 || a.jl1 <= a.jl0 || a.ncols <= 0)
     return;
   TilePanelMap mp;
   mp.sub = (a.nb + Cfg::BM - 1) / Cfg::BM;
   mp.cbn = (a.ncols + Cfg::BN - 1) / Cfg::BN;
-  mp.cnt_s = (a.kinds & 1) ? (long) a.layers_s * (a.il1 - a.il0) * mp.sub * mp.cbn : 0;
-  mp.cnt_t = (a.kinds & 2) ? (long) a.layers_t * (a.jl1 - a.jl0) * mp.sub * mp.cbn : 0;
+  const long per_s = (long) (a.il1 - a.il0) * mp.sub * mp.cbn, per_t = (long) (a.jl1 - a.jl0) * mp.sub * mp.cbn;
+  // fixed-mode kernels: whole slabs (nb a multiple of the slab depth), 16-byte aligned operands
+  constexpr int VE = (16 / (int) sizeof(T)) > 0 ? (16 / (int) sizeof(T)) : 1;
+  static const bool allow_split = [] {
+    const char* e = std::getenv("DLAF_MI355X_TILE_PANEL_SPLIT");
+    return e ? std::atoi(e) != 0 : true;
+  }();
+  const bool fast = allow_split && a.nb % Cfg::BK == 0 && a.nb % VE == 0 && a.ldw % VE == 0 &&
+                    reinterpret_cast<uintptr_t>(a.w) % 16 == 0 && reinterpret_cast<uintptr_t>(a.tiles) % 16 == 0 &&
+                    (a.e0 % VE) == 0 && (a.nt_r > 2 || a.nt_c > 2);
+  mp.chunk_s = a.chunk_s;
+  mp.chunk_t = a.chunk_t;
+  if (fast) {
+    a.split = 1;
+    mp.only_special = 1;
+    mp.layers_s = a.layers_s;
+    mp.layers_t = a.layers_t;
+    mp.base_s = mp.base_t = 0;
+    if (a.kinds & 1) {
+      mp.cnt_s = per_s * a.layers_s;
+      mp.cnt_t = 0;
+      hipLaunchKernelGGL((tile_panel_kernel<T, 0>), dim3((unsigned) mp.cnt_s), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, a, mp);
+    }
+    if (a.kinds & 2) {
+      mp.cnt_s = 0;
+      mp.cnt_t = per_t * a.layers_t;
+      hipLaunchKernelGGL((tile_panel_kernel<T, 1>), dim3((unsigned) mp.cnt_t), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, a, mp);
+    }
+    // the rest: one extra layer per kind
+    mp.base_s = a.layers_s;
+    mp.base_t = a.layers_t;
+    mp.layers_s = mp.layers_t = 1;
+    mp.cnt_s = (a.kinds & 1) ? per_s : 0;
+    mp.cnt_t = (a.kinds & 2) ? per_t : 0;
+    if (mp.cnt_s + mp.cnt_t > 0)
+      hipLaunchKernelGGL((tile_panel_kernel<T, 2>), dim3((unsigned) (mp.cnt_s + mp.cnt_t)), dim3(Cfg::THREADS), Cfg::LDS_BYTES,
+                         stream, a, mp);
+    return;
+  }
+  mp.only_special = 0;
+  mp.layers_s = a.layers_s;
+  mp.layers_t = a.layers_t;
+  mp.base_s = mp.base_t = 0;
+  mp.cnt_s = (a.kinds & 1) ? per_s * a.layers_s : 0;
+  mp.cnt_t = (a.kinds & 2) ? per_t * a.layers_t : 0;
   if (mp.cnt_s + mp.cnt_t == 0)
     return;
-  hipLaunchKernelGGL((tile_panel_kernel<T>), dim3((unsigned) (mp.cnt_s + mp.cnt_t)), dim3(Cfg::THREADS), Cfg::LDS_BYTES,
+  hipLaunchKernelGGL((tile_panel_kernel<T, 2>), dim3((unsigned) (mp.cnt_s + mp.cnt_t)), dim3(Cfg::THREADS), Cfg::LDS_BYTES,
                      stream, a, mp);
 }
 
@@ -1052,8 +1172,12 @@ static void band_init_one() {
   using Cfg = typename GenCfg<T>::type;
   (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              Cfg::LDS_BYTES);
-  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_panel_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             Cfg::LDS_BYTES);
+  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_panel_kernel<T, 0>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_panel_kernel<T, 1>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_panel_kernel<T, 2>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
   (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&panel_qr_kernel<T, 1, kThreads>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
   (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&panel_qr_kernel<T, 1, 1024>),
@@ -1073,7 +1197,7 @@ void band_kernels_init() {
   template void launch_gemm<T>(const GemmArgs<T>&, hipStream_t);                                                       \
   template size_t gemm_partial_elems<T>(int, int, int);                                                                \
   template int gemm_pick_ksplit<T>(int, int, long);                                                                    \
-  template void launch_tile_panel<T>(const TilePanelArgs<T>&, hipStream_t);                                            \
+  template void launch_tile_panel<T>(TilePanelArgs<T>&, hipStream_t);                                            \
   template void launch_hemm_reduce<T>(const TilePanelArgs<T>&, long, T*, long, hipStream_t);                           \
   template void launch_layers_reduce<T>(const T*, int, long, int, T*, long, hipStream_t);                              \
   template void launch_panel_qr<T>(T*, long, int, int, T*, void*, int*, hipStream_t);                                  \

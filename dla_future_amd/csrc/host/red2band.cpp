@@ -115,12 +115,21 @@ int reduction_to_band_device(DeviceMatrix<T>& A, int band, T* taus_host) {
   DLAF_HIP_CHECK(hipMemsetAsync(taus, 0, ((size_t) nrefls + 1) * sizeof(T), s));
   const int ksplit_max = std::max(1, gemm_pick_ksplit<T>(b, b, n));
   T* gpart = dalloc<T>(gemm_partial_elems<T>(b, b, ksplit_max));
-  // partial layers of the xHEMM: layers(out tiles) * out tiles at its maximum over the panels
-  long cap_s = 1, cap_t = 1;
-  for (long ot = 1; ot <= std::max<long>(ltr, 1); ++ot)
-    cap_s = std::max<long>(cap_s, (long) tile_panel_pick_layers(ot, nb, b, std::max<long>(ltc, 1), sizeof(T)) * ot);
-  for (long ot = 1; ot <= std::max<long>(ltc, 1); ++ot)
-    cap_t = std::max<long>(cap_t, (long) tile_panel_pick_layers(ot, nb, b, std::max<long>(ltr, 1), sizeof(T)) * ot);
+  // partial layers of the xHEMM: (layers + 1) * out tiles at its maximum over the panels (trailing matrices of
+  // ot x ot local tiles: the local tile counts shrink together)
+  long cap_s = 2, cap_t = 2;
+  for (long k = 0; k <= std::max(ltr, ltc); ++k) {
+    const long otr = std::max<long>(ltr - k, 0), otc = std::max<long>(ltc - k, 0);
+    if (otr == 0 || otc == 0)
+      break;
+    const int cs = tile_panel_pick_chunk(otr, nb, b, otc, true, sizeof(T));
+    const int ct = tile_panel_pick_chunk(otc, nb, b, otr, true, sizeof(T));
+    cap_s = std::max<long>(cap_s, (long) (tile_panel_layers(otc, cs) + 1) * otr);
+    cap_t = std::max<long>(cap_t, (long) (tile_panel_layers(otr, ct) + 1) * otc);
+    // (rows and columns of a process grid need not shrink in step: one more tile either way)
+    cap_s = std::max<long>(cap_s, (long) (tile_panel_layers(otc + 1, cs) + 1) * (otr + 1));
+    cap_t = std::max<long>(cap_t, (long) (tile_panel_layers(otr + 1, ct) + 1) * (otc + 1));
+  }
   T* part_s = dalloc<T>((size_t) cap_s * nb * (size_t) b);
   T* part_t = dalloc<T>((size_t) cap_t * nb * (size_t) b);
   void* qr_scratch = nullptr;
@@ -251,8 +260,13 @@ int reduction_to_band_device(DeviceMatrix<T>& A, int band, T* taus_host) {
     h.ncols = b;
     // (a rank without local trailing rows or columns has no work items at all: nothing to sum either)
     h.kinds = (il0 < ltr && jl0 < ltc) ? 3 : 0;
-    h.layers_s = tile_panel_pick_layers(ltr - il0, nb, b, std::max<long>(ltc - jl0, 1), sizeof(T));
-    h.layers_t = tile_panel_pick_layers(ltc - jl0, nb, b, std::max<long>(ltr - il0, 1), sizeof(T));
+    h.chunk_s = tile_panel_pick_chunk(ltr - il0, nb, b, std::max<long>(ltc - jl0, 1), true, sizeof(T));
+    h.chunk_t = tile_panel_pick_chunk(ltc - jl0, nb, b, std::max<long>(ltr - il0, 1), true, sizeof(T));
+    h.layers_s = tile_panel_layers(std::max<long>(ltc - jl0, 1), h.chunk_s);
+    h.layers_t = tile_panel_layers(std::max<long>(ltr - il0, 1), h.chunk_t);
+    if ((size_t) (h.layers_s + 1) * (size_t) (ltr - il0) > (size_t) cap_s || (size_t) (h.layers_t + 1) * (size_t) (ltc - jl0) > (size_t) cap_t)
+      fatal("[dlaf_mi355x] reduction_to_band: partial-layer workspace too small (%d x %ld, %d x %ld; caps %ld, %ld)\n",
+            h.layers_s + 1, ltr - il0, h.layers_t + 1, ltc - jl0, cap_s, cap_t);
     h.part_s = part_s;
     h.part_t = part_t;
     if (lookahead && p > 0)
@@ -437,9 +451,11 @@ int bt_reduction_to_band_device(int band, TileMatrix<T>& C, DeviceMatrix<T>& A, 
   DLAF_HIP_CHECK(hipMemsetAsync(W, 0, (size_t) ldp * nb * sizeof(T), s));
   const int ksplit_max = std::max(1, gemm_pick_ksplit<T>(nb, nb, n));
   T* gpart = dalloc<T>(gemm_partial_elems<T>(nb, nb, ksplit_max));
-  long lay_cap = 1;
-  for (long ot = 1; ot <= std::max<long>(cltc, 1); ++ot)
-    lay_cap = std::max<long>(lay_cap, (long) tile_panel_pick_layers(ot, nb, nb, std::max<long>(cltr, 1), sizeof(T)) * ot);
+  long lay_cap = 2;
+  for (long src = 1; src <= std::max<long>(cltr, 1); ++src) {
+    const int ch = tile_panel_pick_chunk(std::max<long>(cltc, 1), nb, nb, src, false, sizeof(T));
+    lay_cap = std::max<long>(lay_cap, (long) (tile_panel_layers(src, ch) + 1) * std::max<long>(cltc, 1));
+  }
   T* part_t = dalloc<T>((size_t) lay_cap * nb * (size_t) nb);
 
   hipEvent_t ev0, ev1;
@@ -534,11 +550,13 @@ int bt_reduction_to_band_device(int band, TileMatrix<T>& C, DeviceMatrix<T>& A, 
       h.e0 = e0;
       h.ncols = nrefl;
       h.kinds = 2;
-      h.layers_t = tile_panel_pick_layers(cltc, nb, nrefl, std::max<long>(cltr - il0, 1), sizeof(T));
+      h.chunk_t = tile_panel_pick_chunk(cltc, nb, nrefl, std::max<long>(cltr - il0, 1), false, sizeof(T));
+      h.layers_t = tile_panel_layers(std::max<long>(cltr - il0, 1), h.chunk_t);
       h.part_t = part_t;
       if (il0 < cltr) {
         launch_tile_panel(h, s);
-        launch_layers_reduce(part_t, h.layers_t, cltc * nb, nrefl, W2H, ldw2, s);
+        // (every tile column of C has the same cltr - il0 sources: all layers_t runs exist, + the extra layer)
+        launch_layers_reduce(part_t, h.layers_t + h.split, cltc * nb, nrefl, W2H, ldw2, s);
       }
       else {
         DLAF_HIP_CHECK(hipMemsetAsync(W2H, 0, (size_t) ldw2 * nrefl * sizeof(T), s));
