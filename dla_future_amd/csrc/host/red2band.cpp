@@ -373,7 +373,8 @@ int reduction_to_band_device(DeviceMatrix<T>& A, int band, T* taus_host) {
   float ms = 0;
   DLAF_HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
   g_last_ms = ms;
-  g_last_flops = (TypeInfo<T>::is_complex ? 4.0 : 1.0) * 4.0 / 3.0 * (double) n * (double) n * (double) n;
+  // miniapp_reduction_to_band.cpp:163-168: add_mul = 2/3 n^3 - n^2 nb, one add + one mul each (x4 complex)
+  g_last_flops = (TypeInfo<T>::is_complex ? 4.0 : 1.0) * 2.0 * (2.0 / 3.0 * (double) n * n * n - (double) n * n * nb);
   DLAF_HIP_CHECK(hipEventDestroy(ev0));
   DLAF_HIP_CHECK(hipEventDestroy(ev1));
   for (int q = 0; q < 2; ++q) {
@@ -603,7 +604,8 @@ int bt_reduction_to_band_device(int band, TileMatrix<T>& C, DeviceMatrix<T>& A, 
   float ms = 0;
   DLAF_HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
   g_last_ms = ms;
-  g_last_flops = (TypeInfo<T>::is_complex ? 4.0 : 1.0) * 2.0 * (double) n * (double) n * (double) ccols.n;
+  // miniapp_bt_reduction_to_band.cpp:160-164: add_mul = (m - b)^2 n
+  g_last_flops = (TypeInfo<T>::is_complex ? 4.0 : 1.0) * 2.0 * (double) (n - b) * (double) (n - b) * (double) ccols.n;
   DLAF_HIP_CHECK(hipEventDestroy(ev0));
   DLAF_HIP_CHECK(hipEventDestroy(ev1));
   for (T* q : {qt, V, W, S, Tm, W2H, taus, gpart, part_t})

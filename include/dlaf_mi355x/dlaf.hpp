@@ -426,6 +426,87 @@ void generalized_to_standard(blas::Uplo uplo, Matrix<T, Device::CPU>& mat_a, Mat
 }
 }  // namespace eigensolver::internal
 
+// include/dlaf/eigensolver/reduction_to_band.h:40-122 and bt_reduction_to_band.h (first stage).
+// The reference returns the taus as a Matrix<T, Device::CPU> distributed over the process columns; here every
+// process gets all n - band_size - 1 of them as a std::vector (entry j belongs to the reflector in global column j).
+inline SizeType get_band_size(SizeType nb) { return dlaf_mi355x_get_band_size((int) nb); }
+namespace eigensolver::internal {
+template <Backend B, class T>
+std::vector<T> reduction_to_band(comm::CommunicatorGrid& grid, Matrix<T, Device::GPU>& mat_a, SizeType band_size) {
+  static_assert(B == Backend::GPU, "this library has no CPU backend");
+  if (mat_a.uplo() != blas::Uplo::Lower)
+    dlaf::internal::fail("reduction_to_band references the lower triangle (reduction_to_band.h:66-68)");
+  if (grid.context() != mat_a.context())
+    dlaf::internal::fail("matrix::equal_process_grid(mat_a, grid)");
+  const SizeType n = mat_a.size().rows();
+  std::vector<T> taus((size_t) std::max<SizeType>(0, n - band_size - 1));
+  if (dlaf_mi355x_reduction_to_band_device(mat_a.handle(), (int) band_size, taus.empty() ? nullptr : taus.data()) != 0)
+    dlaf::internal::fail("reduction_to_band");
+  return taus;
+}
+template <Backend B, class T>
+std::vector<T> reduction_to_band(comm::CommunicatorGrid& grid, Matrix<T, Device::CPU>& mat_a, SizeType band_size) {
+  static_assert(B == Backend::GPU, "this library has no CPU backend");
+  const auto& d = mat_a.distribution();
+  const DLAF_descriptor desc{(int) d.size().rows(), (int) d.size().cols(), (int) d.block_size().rows(),
+                             (int) d.block_size().cols(), (int) d.source_rank_index().row(),
+                             (int) d.source_rank_index().col(), 0, 0, (int) mat_a.ld()};
+  std::vector<T> taus((size_t) std::max<SizeType>(0, d.size().rows() - band_size - 1));
+  T dummy{};
+  T* tp = taus.empty() ? &dummy : taus.data();
+  int r;
+  if constexpr (std::is_same_v<T, float>)
+    r = dlaf_mi355x_reduction_to_band_s(grid.context(), mat_a.ptr(), desc, (int) band_size, tp);
+  else if constexpr (std::is_same_v<T, double>)
+    r = dlaf_mi355x_reduction_to_band_d(grid.context(), mat_a.ptr(), desc, (int) band_size, tp);
+  else if constexpr (std::is_same_v<T, std::complex<float>>)
+    r = dlaf_mi355x_reduction_to_band_c(grid.context(), reinterpret_cast<dlaf_complex_c*>(mat_a.ptr()), desc,
+                                        (int) band_size, reinterpret_cast<dlaf_complex_c*>(tp));
+  else
+    r = dlaf_mi355x_reduction_to_band_z(grid.context(), reinterpret_cast<dlaf_complex_z*>(mat_a.ptr()), desc,
+                                        (int) band_size, reinterpret_cast<dlaf_complex_z*>(tp));
+  if (r != 0)
+    dlaf::internal::fail("reduction_to_band");
+  return taus;
+}
+template <Backend B, class T>
+std::vector<T> reduction_to_band(Matrix<T, Device::CPU>& mat_a, SizeType band_size) {
+  comm::CommunicatorGrid grid = comm::CommunicatorGrid::single();
+  return reduction_to_band<B, T>(grid, mat_a, band_size);
+}
+// C <- Q C (host-resident operands): mat_v = what reduction_to_band left, taus = what it returned
+template <Backend B, class T>
+void bt_reduction_to_band(comm::CommunicatorGrid& grid, SizeType band_size, Matrix<T, Device::CPU>& mat_c,
+                          Matrix<T, Device::CPU>& mat_v, const std::vector<T>& taus) {
+  static_assert(B == Backend::GPU, "this library has no CPU backend");
+  auto desc_of = [](const Matrix<T, Device::CPU>& m) {
+    const auto& d = m.distribution();
+    return DLAF_descriptor{(int) d.size().rows(), (int) d.size().cols(), (int) d.block_size().rows(),
+                           (int) d.block_size().cols(), (int) d.source_rank_index().row(),
+                           (int) d.source_rank_index().col(), 0, 0, (int) m.ld()};
+  };
+  T dummy{};
+  const T* tp = taus.empty() ? &dummy : taus.data();
+  int r;
+  if constexpr (std::is_same_v<T, float>)
+    r = dlaf_mi355x_bt_reduction_to_band_s(grid.context(), (int) band_size, mat_c.ptr(), desc_of(mat_c), mat_v.ptr(),
+                                           desc_of(mat_v), tp);
+  else if constexpr (std::is_same_v<T, double>)
+    r = dlaf_mi355x_bt_reduction_to_band_d(grid.context(), (int) band_size, mat_c.ptr(), desc_of(mat_c), mat_v.ptr(),
+                                           desc_of(mat_v), tp);
+  else if constexpr (std::is_same_v<T, std::complex<float>>)
+    r = dlaf_mi355x_bt_reduction_to_band_c(grid.context(), (int) band_size, reinterpret_cast<dlaf_complex_c*>(mat_c.ptr()),
+                                           desc_of(mat_c), reinterpret_cast<const dlaf_complex_c*>(mat_v.ptr()),
+                                           desc_of(mat_v), reinterpret_cast<const dlaf_complex_c*>(tp));
+  else
+    r = dlaf_mi355x_bt_reduction_to_band_z(grid.context(), (int) band_size, reinterpret_cast<dlaf_complex_z*>(mat_c.ptr()),
+                                           desc_of(mat_c), reinterpret_cast<const dlaf_complex_z*>(mat_v.ptr()),
+                                           desc_of(mat_v), reinterpret_cast<const dlaf_complex_z*>(tp));
+  if (r != 0)
+    dlaf::internal::fail("bt_reduction_to_band");
+}
+}  // namespace eigensolver::internal
+
 // include/dlaf/init.h: the library needs no runtime arguments; initialize / finalize are idempotent
 inline void initialize(int argc = 0, const char** argv = nullptr) { dlaf_initialize(argc, argv, 0, nullptr); }
 inline void finalize() { dlaf_finalize(); }

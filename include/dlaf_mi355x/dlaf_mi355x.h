@@ -234,7 +234,8 @@ DLAF_EXTERN_C int dlaf_mi355x_bt_reduction_to_band_z(int context, int band_size,
 /* get_band_size (include/dlaf/eigensolver/internal/get_band_size.h:20-31, eigensolver_min_band = 100): the band the
  * reference's eigensolver picks for a block size (128 for nb = 512) */
 DLAF_EXTERN_C int dlaf_mi355x_get_band_size(int nb) DLAF_NOEXCEPT;
-/* device time (ms, HIP events) and whole-grid algorithmic flops (4/3 n^3, resp. 2 n^2 k; x4 complex) of the last
+/* device time (ms, HIP events) and whole-grid flops in the reference miniapps' models (2 (2/3 n^3 - n^2 nb), resp.
+ * 2 (n - band)^2 k; x4 complex: miniapp_reduction_to_band.cpp:163-168, miniapp_bt_reduction_to_band.cpp:160-164) of the last
  * reduction_to_band / bt_reduction_to_band on this process */
 DLAF_EXTERN_C int dlaf_mi355x_red2band_profile(double* ms, double* flops) DLAF_NOEXCEPT;
 

@@ -62,6 +62,7 @@ def test_miniapp_compiles():
     assert os.path.exists(build_miniapp())
     assert os.path.exists(build_miniapp(name="miniapp_triangular_solver"))
     assert os.path.exists(build_miniapp(name="miniapp_gen_to_std"))
+    assert os.path.exists(build_miniapp(name="miniapp_reduction_to_band"))
 
 
 def check_miniapp_output(out, nruns, nchecks):
@@ -127,3 +128,19 @@ def test_miniapp_gen_to_std():
         assert len(re.findall(r"^\[\d+\] [0-9.e+-]+s [0-9.e+-]+GFlop/s %s%s \(1500, 1500\) \(128, 128\) \(1, 1\) 1 GPU" % (tp, uplo),
                               r.stdout, flags=re.M)) == 2, r.stdout
         assert r.stdout.count("CSVData-2, run, ") == 2, r.stdout
+
+
+@pytest.mark.gpu
+def test_miniapp_reduction_to_band():
+    """miniapp_reduction_to_band.cpp: the reference's options (incl. --band-size) and result lines; the matrix resident
+    on the device in the timed window."""
+    import re
+    exe = build_miniapp(name="miniapp_reduction_to_band")
+    for tp, band in (("d", "64"), ("z", "128")):
+        r = subprocess.run([exe, "--matrix-size", "1500", "--block-size", "128", "--band-size", band, "--type", tp, "--nruns", "2",
+                            "--csv"], cwd=ROOT, capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, DLAF_MI355X_DEVICE="0"))
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        assert len(re.findall(r"^\[\d+\] [0-9.e+-]+s [0-9.e+-]+GFlop/s %s \(1500, 1500\) \(128, 128\) %s \(1, 1\) 1 GPU" % (tp, band),
+                              r.stdout, flags=re.M)) == 2, r.stdout
+        assert r.stdout.count("CSVData-2, run, ") == 2 and "band_size, " + band in r.stdout, r.stdout
