@@ -34,6 +34,12 @@ struct UpdateCfg<double> {
   // L2 -> LDS bytes per flop than two independent 128 x 128 blocks
   using type = BlockCfg<double, 256, 128, 64, 64, 16, true, DLAF_UPD_BIG, 512>;
   static constexpr int min_waves = 2;
+#elif defined(DLAF_UPD_WIDE4)
+  // tuning aid (round 3): 256 x 128 block on FOUR waves (2 x 2 wave tiles of 128 x 64 = 8 x 4 MFMA tiles, 256
+  // accumulator registers: one wave per SIMD, one workgroup per compute unit) -- the "fewer LDS bytes per flop"
+  // variant of DESIGN section 8.2: 0.375 fragment reads per MFMA instead of 0.5, 25 % fewer L2 -> LDS bytes
+  using type = BlockCfg<double, 256, 128, 128, 64, 16, true, DLAF_UPD_WIDE4, 256>;
+  static constexpr int min_waves = 1;
 #elif defined(DLAF_UPD_BK) && defined(DLAF_UPD_ST)
   // tuning aid (tools/run_ab_ring.sh): slab depth / ring depth of the direct-to-LDS pipeline
   using type = BlockCfg<double, 128, 128, 64, 64, DLAF_UPD_BK, true, DLAF_UPD_ST>;
@@ -76,7 +82,9 @@ struct UpdateMap {
 };
 
 // One work item = one BM x BN block of one tile.  Returns early for blocks outside the domain.
-template <class T, bool VEC, bool UTAIL = false>
+// PART: 0 every block; 1 only the interior blocks (whole BM x BN, whole slabs, no triangle mask: the K loop on the
+// direct-to-LDS path + the wide epilogue, nothing else compiled in); 2 only the others (edge / masked blocks)
+template <class T, bool VEC, bool UTAIL = false, int PART = 0>
 __device__ __forceinline__ void update_block(const UpdateArgs<T>& p, const UpdateMap& mp, long w,
                                              real_t<T>* __restrict__ lds, int s0 = 0) {
   using Cfg = typename UpdateCfg<T>::type;
@@ -190,6 +198,12 @@ __device__ __forceinline__ void update_block(const UpdateArgs<T>& p, const Updat
   B2 = uniform(B2);
 #endif
   const bool full = (mrows == Cfg::BM) && (ncols == Cfg::BN) && (p.K % Cfg::BK == 0) && (p.K1 % Cfg::BK == 0);
+  if constexpr (PART != 0) {
+    const bool interior = full && !(diag && m0 < n0 + ncols - 1) && VEC && ((p.ldc * (long) sizeof(T)) % 16 == 0) &&
+                          (reinterpret_cast<uintptr_t>(C) % 16 == 0);
+    if ((PART == 1) != interior)
+      return;
+  }
   Acc<Cfg> acc;
 #ifndef DLAF_UPD_PRELOAD
 #define DLAF_UPD_PRELOAD 1
@@ -242,11 +256,17 @@ __device__ __forceinline__ void update_block(const UpdateArgs<T>& p, const Updat
     }
   }
   acc.clear();
-  if (full)
+  if constexpr (PART == 1) {
     gemm_nt_block<Cfg, T, VEC, false, UTAIL>(A, DLAF_LDA_X, mrows, B, DLAF_LDB_X, ncols, p.K, lds, acc, K1, A2, B2,
                                              s0);
-  else
-    gemm_nt_block<Cfg, T, false, true>(A, p.lda, mrows, B, ldb, ncols, p.K, lds, acc, K1, A2, B2);
+  }
+  else {
+    if (full)
+      gemm_nt_block<Cfg, T, VEC, false, UTAIL>(A, DLAF_LDA_X, mrows, B, DLAF_LDB_X, ncols, p.K, lds, acc, K1, A2, B2,
+                                               s0);
+    else
+      gemm_nt_block<Cfg, T, false, true>(A, p.lda, mrows, B, ldb, ncols, p.K, lds, acc, K1, A2, B2);
+  }
 
 #ifdef DLAF_DBG_SKIP_EPILOGUE
   {
@@ -264,12 +284,13 @@ __device__ __forceinline__ void update_block(const UpdateArgs<T>& p, const Updat
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave % Cfg::WAVES_M, wn = wave / Cfg::WAVES_M;
   const int g = lane >> 4, c = lane & 15;
-  const bool masked = !full || (diag && m0 < n0 + ncols - 1);
+  const bool masked = PART == 1 ? false : (!full || (diag && m0 < n0 + ncols - 1));
   if constexpr (Cfg::PAIRED) {
     // lane holds rows (m, m+1) of tiles (2q, 2q+1): 16-byte accesses when the tile column is aligned
     typedef R r2 __attribute__((ext_vector_type(2)));
-    const bool wide = !masked && VEC && ((p.ldc * (long) sizeof(T)) % 16 == 0) &&
-                      (reinterpret_cast<uintptr_t>(C) % 16 == 0);
+    const bool wide = PART == 1 ? true
+                                : (!masked && VEC && ((p.ldc * (long) sizeof(T)) % 16 == 0) &&
+                                   (reinterpret_cast<uintptr_t>(C) % 16 == 0));
 #ifndef DLAF_EPI_COLS
 #define DLAF_EPI_COLS 4  // A/B on one MI355X (tools/run_ab_epi.sh): 1 -> 4 columns per round trip +0.7 ... 1.2 % on the bulk launches
 #endif
@@ -389,7 +410,11 @@ __global__ __launch_bounds__(UpdateCfg<T>::type::THREADS, UpdateCfg<T>::min_wave
   if (!mp.persist) {
     const long v = blockIdx.x;
     const long w = mp.xcd ? (v & 7) * (mp.total >> 3) + (v >> 3) : v;
+#ifdef DLAF_UPD_LEAN
+    update_block<T, VEC, false, (ROLE == 0 ? 1 : 0)>(p, mp, w, lds);
+#else
     update_block<T, VEC>(p, mp, w, lds);
+#endif
     return;
   }
   // persistent: workgroups with the same id mod 8 (same XCD under round-robin dispatch) drain the
@@ -446,7 +471,11 @@ __global__ __launch_bounds__(UpdateCfg<T>::type::THREADS, UpdateCfg<T>::min_wave
       }
       __syncthreads();
     }
+#ifdef DLAF_UPD_LEAN
+    update_block<T, VEC, ROLE == 0, (ROLE == 0 ? 1 : 0)>(p, mp, (long) q * per_q + i, lds, s0);
+#else
     update_block<T, VEC, ROLE == 0>(p, mp, (long) q * per_q + i, lds, s0);
+#endif
     if (mp.lockstep && threadIdx.x == 0)
       __hip_atomic_fetch_add(&mp.counters[8 + q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }

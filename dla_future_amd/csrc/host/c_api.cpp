@@ -2,12 +2,18 @@
 // (include/dlaf_c/{init,grid,utils}.h, include/dlaf_c/factorization/cholesky.h; implemented upstream
 // in src/c_api/{init,grid,utils}.cpp and src/c_api/factorization/cholesky.{h,cpp}) plus the
 // MI355X extensions declared in include/dlaf_mi355x/dlaf_mi355x.h.
+// (the core never sees <mpi.h>: the MPI-typed prototypes of dlaf_c/grid.h stay out of this translation unit, which
+// defines forwarders with a pointer-sized first parameter under the same names)
+#define DLAF_MI355X_NO_MPI 1
+#include <dlfcn.h>
+
 #include <climits>
 #include <complex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <string>
 #include <unordered_map>
 
 #include <dlaf_c/factorization/cholesky.h>
@@ -288,6 +294,34 @@ int dispatch_type(char type, F&& f) {
 }  // namespace
 
 struct dlaf_mi355x_matrix_s : MatrixHandle {};
+
+namespace {
+static void* mpi_shim_handle() {
+  static void* handle = []() -> void* {
+    Dl_info info;
+    std::string path = "libdlaf_mi355x_mpi.so";
+    if (dladdr(reinterpret_cast<void*>(&dlaf_free_grid), &info) != 0 && info.dli_fname != nullptr) {
+      std::string self = info.dli_fname;
+      const size_t slash = self.rfind('/');
+      if (slash != std::string::npos)
+        path = self.substr(0, slash + 1) + path;
+    }
+    void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (h == nullptr)
+      fatal("[dlaf_mi355x] the MPI-typed grid entry points need %s (built by `make -C dla_future_amd/csrc mpi` when an "
+            "MPI is installed): %s\n", path.c_str(), dlerror());
+    return h;
+  }();
+  return handle;
+}
+template <class F>
+static F mpi_shim_symbol(const char* name, F self) {
+  F f = reinterpret_cast<F>(dlsym(mpi_shim_handle(), name));
+  if (f == nullptr || f == self)
+    fatal("[dlaf_mi355x] libdlaf_mi355x_mpi.so does not define %s\n", name);
+  return f;
+}
+}  // namespace
 
 // =================================================================================== dlaf_c
 extern "C" {
@@ -791,6 +825,31 @@ long dlaf_mi355x_dist_local_size(long n, int nb, int gs, int rank, int src) noex
 }
 long dlaf_mi355x_dist_local_tiles(long n, int nb, int gs, int rank, int src) noexcept {
   return Axis{n, nb, gs, rank, src}.local_tiles();
+}
+
+
+// ---- MPI-typed entries of the reference's grid.h (dlaf_create_grid, grid_ordering, dlaf_create_grid_from_blacs) -----
+// They live in the optional shim libdlaf_mi355x_mpi.so (mpi_grid.cpp), the only object of this build that sees
+// <mpi.h>.  So that a caller of the reference's interface can link -ldlaf_mi355x alone, as it links -ldlaf upstream,
+// the core exports forwarders under the same names: the first call loads the shim from this library's directory and
+// jumps to its definition.  MPI_Comm is an int (MPICH ABI) or a pointer (Open MPI): either way the first integer
+// argument register of the x86-64 psABI, which a forwarder declared with a pointer-sized first parameter passes on
+// untouched.  A program that links the shim itself binds to the shim's definitions directly (it comes first in the
+// link order) and never gets here.
+int dlaf_create_grid(void* comm, int nprow, int npcol, char order) noexcept {
+  using fn = int (*)(void*, int, int, char);
+  static const fn f = mpi_shim_symbol<fn>("dlaf_create_grid", &dlaf_create_grid);
+  return f(comm, nprow, npcol, order);
+}
+char grid_ordering(void* comm, int nprow, int npcol, int myprow, int mypcol) noexcept {
+  using fn = char (*)(void*, int, int, int, int);
+  static const fn f = mpi_shim_symbol<fn>("grid_ordering", &grid_ordering);
+  return f(comm, nprow, npcol, myprow, mypcol);
+}
+void dlaf_create_grid_from_blacs(int blacs_ctxt) noexcept {
+  using fn = void (*)(int);
+  static const fn f = mpi_shim_symbol<fn>("dlaf_create_grid_from_blacs", &dlaf_create_grid_from_blacs);
+  f(blacs_ctxt);
 }
 
 }  // extern "C"

@@ -62,6 +62,10 @@ int gen_to_std_device(DeviceMatrix<T>& A, DeviceMatrix<T>& L) {
   const CommAxis ax_col = A.transposed ? CommAxis::Row : CommAxis::Col;
   hipStream_t s = A.s_high;
   int* info = A.info;
+  // work enqueued on the factor's streams (a cholesky_start without a wait) must be done before it is read here
+  for (hipStream_t ls : {L.s_high, L.s_low, L.s_comm})
+    if (ls != nullptr && ls != s)
+      DLAF_HIP_CHECK(hipStreamSynchronize(ls));
   DLAF_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int), s));
   if (nt == 0)
     return 0;
@@ -288,6 +292,13 @@ int gen_to_std_device(DeviceMatrix<T>& A, DeviceMatrix<T>& L) {
   DLAF_HIP_CHECK(hipStreamSynchronize(s));
   for (T* p : {dws, dfull, xt, pA, pL, pAT, pLT, Tw})
     DLAF_HIP_CHECK(hipFree(p));
+  if (dist) {
+    // the same value on every rank, as DeviceMatrix::wait() makes it for the factorization (MIN of the positive flags)
+    constexpr double kTop = 2147483648.0;
+    double v[2] = {h > 0 ? kTop - (double) h : 0.0, h == kInfoSchedulingFailure ? 1.0 : 0.0};
+    tr->allreduce_max(v, 2, grid->nprow, grid->npcol, grid->myrow, grid->mycol);
+    h = v[1] > 0 ? kInfoSchedulingFailure : (v[0] > 0 ? (int) (kTop - v[0]) : 0);
+  }
   return h;
 }
 

@@ -31,6 +31,13 @@ struct MpiComms {
   MPI_Comm world = MPI_COMM_NULL, row = MPI_COMM_NULL, col = MPI_COMM_NULL;
 };
 std::map<int, std::unique_ptr<MpiComms>> g_comms;  // kept alive as long as the grid
+// Set when this library's statics are being torn down (constructed after g_comms, so destroyed before it).  The core
+// library -- a dependency of this one, hence destroyed LATER -- frees the grids a program never freed from its own
+// static destructors and calls release_comms for each: by then g_comms and the MpiComms it owned are gone.
+bool g_shutdown = false;
+struct ShutdownFlag {
+  ~ShutdownFlag() { g_shutdown = true; }
+} g_shutdown_flag;
 
 int host_bcast(void* user, int axis, int root, void* buf, size_t bytes) {
   auto* c = static_cast<MpiComms*>(user);
@@ -51,6 +58,8 @@ int host_barrier(void* user) {
 
 // dlaf_free_grid / dlaf_finalize of the core library end here: drop this grid's communicators
 void release_comms(void* user) {
+  if (g_shutdown)
+    return;  // process exit: the communicators went with g_comms (or with MPI_Finalize)
   auto* c = static_cast<MpiComms*>(user);
   int finalized = 0;
   MPI_Finalized(&finalized);

@@ -3,11 +3,21 @@
  * handed out downwards from INT_MAX exactly like upstream (grid.cpp:31) so they cannot collide
  * with BLACS contexts.
  *
- * The MPI-typed entry points exist only when the library was built with DLAF_MI355X_WITH_MPI
- * (libdlaf_mi355x_mpi.so); the MI355X build talks RCCL over xGMI, so a grid can also be made
- * without MPI through include/dlaf_mi355x/dlaf_mi355x.h (dlaf_mi355x_create_grid_rccl). */
+ * The MPI-typed entry points are declared, as upstream declares them unconditionally (grid.h:31,54,71),
+ * whenever <mpi.h> can be found -- no macro needed; DLAF_MI355X_WITH_MPI forces them on, DLAF_MI355X_NO_MPI off.
+ * They are implemented by libdlaf_mi355x_mpi.so (built when an MPI is installed); a program that links only
+ * -ldlaf_mi355x reaches them too: the core library exports the same three symbols as forwarders that load the
+ * shim from the library's own directory on first use (csrc/host/c_api.cpp).  The MI355X build talks RCCL over
+ * xGMI, so a grid can also be made without MPI through include/dlaf_mi355x/dlaf_mi355x.h
+ * (dlaf_mi355x_create_grid_rccl). */
 #pragma once
 #include <dlaf_c/utils.h>
+
+#if !defined(DLAF_MI355X_WITH_MPI) && !defined(DLAF_MI355X_NO_MPI) && defined(__has_include)
+#if __has_include(<mpi.h>)
+#define DLAF_MI355X_WITH_MPI 1
+#endif
+#endif
 
 #ifdef DLAF_MI355X_WITH_MPI
 #include <mpi.h>

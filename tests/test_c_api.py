@@ -65,12 +65,12 @@ def build_blacs():
     return out
 
 
-def run(exe, nprow, npcol, order, timeout, env_extra=None):
+def run(exe, nprow, npcol, order, timeout, env_extra=None, extra=None):
     env = dict(os.environ, DLAF_MI355X_MPI_TRANSPORT="host", DLAF_MI355X_DEVICE="0", OMP_NUM_THREADS="1")
     env.pop("LOCAL_RANK", None)
     env.update(env_extra or {})
-    r = subprocess.run([MPIEXEC, "-n", str(nprow * npcol), exe, str(nprow), str(npcol), order], cwd=ROOT, env=env,
-                       capture_output=True, text=True, timeout=timeout)
+    r = subprocess.run([MPIEXEC, "-n", str(nprow * npcol), exe, str(nprow), str(npcol), order] + list(extra or []), cwd=ROOT,
+                       env=env, capture_output=True, text=True, timeout=timeout)
     return r
 
 
@@ -128,3 +128,37 @@ def test_pdpotrf_on_a_blacs_context(nprow, npcol, order):
     r = subprocess.run([MPIEXEC, "-n", str(nprow * npcol), exe, str(nprow), str(npcol), order, "factorize"], cwd=ROOT,
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "BLACS_GRID_TEST OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def build_plain():
+    """tests/c_api/test_plain_link.c: NO macro of this repository, linked against -ldlaf_mi355x alone (+ the caller's MPI):
+    the reference's headers declare dlaf_create_grid / grid_ordering unconditionally (grid.h:31,54) and a caller links
+    -ldlaf; here <mpi.h> on the include path switches the declarations on and the core library forwards to the shim."""
+    build("test_grid_mpi")  # makes sure the shim and its private link directory exist
+    out = os.path.join(ROOT, "tests", "c_api", "test_plain_link")
+    src = out + ".c"
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        inc = os.path.join(os.path.dirname(os.path.dirname(MPICC)), "include")
+        subprocess.run(["gcc", "-std=c11", "-O1", "-Wall", "-Werror", src, "-I", os.path.join(ROOT, "include"), "-I", inc, "-L", LIB,
+                        "-L", os.path.join(LIB, "mpi"), "-ldlaf_mi355x", "-lmpi", "-lm", f"-Wl,-rpath-link,{LIB}/mpi",
+                        f"-Wl,-rpath,{LIB}", f"-Wl,-rpath,{LIB}/mpi", "-Wl,-rpath,/opt/rocm/lib", "-o", out], check=True)
+    needed = subprocess.run(["readelf", "-d", out], capture_output=True, text=True, check=True).stdout
+    assert "libdlaf_mi355x.so" in needed and "libdlaf_mi355x_mpi.so" not in needed   # the shim is NOT linked
+    return out
+
+
+@pytest.mark.parametrize("nprow,npcol,order", [(1, 1, "R"), (2, 2, "C"), (3, 2, "R")])
+def test_reference_call_sequence_links_against_the_core_library_alone_cpu(nprow, npcol, order):
+    exe = build_plain()
+    r = run(exe, nprow, npcol, order, 120, extra=["cpu"])
+    assert r.returncode == 0 and "PLAIN_LINK_TEST OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nprow,npcol,order", [(1, 1, "R"), (2, 2, "C")])
+def test_reference_call_sequence_links_against_the_core_library_alone(nprow, npcol, order):
+    from conftest import gpu_process_budget
+    gpu_process_budget(nprow * npcol)
+    exe = build_plain()
+    r = run(exe, nprow, npcol, order, 600)
+    assert r.returncode == 0 and "PLAIN_LINK_TEST OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
