@@ -218,8 +218,10 @@ __device__ __forceinline__ void coop_mma64(const real_t<T>* A, const real_t<T>* 
 }
 
 // the same with the row operand in registers: a_re[k4] / a_im[k4] = A[m = wave*16 + c][k = 4 k4 + g]; the
-// accumulators are NOT cleared (the caller preloads them, e.g. with the block the product is subtracted from)
-template <class T>
+// accumulators are NOT cleared (the caller preloads them, e.g. with the block the product is subtracted from).
+// SUB: acc -= A B^H instead of +=.  Every sign sits in the MFMA's negate bit (Mma::mma_neg): a negated copy of the
+// operand registers would be loop-invariant, hoisted, and cost 32 registers the kernel does not have.
+template <class T, bool SUB>
 __device__ __forceinline__ void coop_mma64_rega(const real_t<T> (&a_re)[16], const real_t<T> (&a_im)[16],
                                                 const real_t<T>* B, typename Mma<real_t<T>>::acc_t (&re)[4],
                                                 typename Mma<real_t<T>>::acc_t (&im)[4]) {
@@ -234,10 +236,18 @@ __device__ __forceinline__ void coop_mma64_rega(const real_t<T> (&a_re)[16], con
     for (int j = 0; j < 4; ++j) {
       const R b_re = B[kk * C::LD + j * 16 + c];
       const R b_im = B[C::IMG + kk * C::LD + j * 16 + c];
-      re[j] = Mma<R>::mma(b_re, a_re[k4], re[j]);
-      re[j] = Mma<R>::mma(b_im, a_im[k4], re[j]);
-      im[j] = Mma<R>::mma(b_re, a_im[k4], im[j]);
-      im[j] = Mma<R>::mma(b_im, -a_re[k4], im[j]);
+      if constexpr (!SUB) {
+        re[j] = Mma<R>::mma(b_re, a_re[k4], re[j]);
+        re[j] = Mma<R>::mma(b_im, a_im[k4], re[j]);
+        im[j] = Mma<R>::mma(b_re, a_im[k4], im[j]);
+        im[j] = Mma<R>::mma_neg(b_im, a_re[k4], im[j]);
+      }
+      else {
+        re[j] = Mma<R>::mma_neg(b_re, a_re[k4], re[j]);
+        re[j] = Mma<R>::mma_neg(b_im, a_im[k4], re[j]);
+        im[j] = Mma<R>::mma_neg(b_re, a_im[k4], im[j]);
+        im[j] = Mma<R>::mma(b_im, a_re[k4], im[j]);
+      }
     }
   }
 }
@@ -341,17 +351,17 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
         xre[jt] = acc_t{0, 0, 0, 0};
         xim[jt] = acc_t{0, 0, 0, 0};
       }
-      coop_mma64_rega<T>(a_re, a_im, Bimg, xre, xim);
-      // X_s(m, n = 16 jt + g + 4 v) = operand element k4 = 4 jt + v of the updates below, NEGATED there so that
-      // the MFMAs accumulate C - X_s X_c^H on top of the preloaded C block
+      coop_mma64_rega<T, false>(a_re, a_im, Bimg, xre, xim);
+      // X_s(m, n = 16 jt + g + 4 v) = operand element k4 = 4 jt + v of the updates below, which accumulate
+      // C - X_s X_c^H on top of the preloaded C block
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           if (m_ok)
             store_wt(at(Asj + (long) (16 * jt + 4 * v) * ld, lane_off), make_el<T>(xre[jt][v], xim[jt][v]));
-          a_re[4 * jt + v] = -xre[jt][v];
-          a_im[4 * jt + v] = -xim[jt][v];
+          a_re[4 * jt + v] = xre[jt][v];
+          a_im[4 * jt + v] = xim[jt][v];
         }
       coop_publish(&xflag[(long) j * G + s], 1u, false);
       if (s - j - 1 > 0 && !coop_wait_all(&xflag[(long) j * G + j + 1], s - j - 1, &wait_slot, spin_limit)) {
@@ -365,14 +375,21 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
         const int rows_c = min(kCB, kb - kCB * cc);
         T* Csc = tile + (long) kCB * s + (long) kCB * cc * ld;
         const bool diag = (cc == s);
+        // the lane parts of every address and predicate below are made opaque once per block: computed from loop
+        // invariants they would all be hoisted out of this loop (16 global offsets, 32 LDS addresses, 16 masks) and
+        // spilled; recomputed here they are an add or an immediate offset each
+        unsigned lo = lane_off;
+        int ml = m, gl = g;
+        asm volatile("" : "+v"(lo), "+v"(ml), "+v"(gl));
+        const bool ml_ok = ml < rows_s;
         acc_t ure[4], uim[4];
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
-            const int n = jt * 16 + 4 * v + g;
-            const T el = (m_ok && n < rows_c && (!diag || m >= n)) ? *at(Csc + (long) (16 * jt + 4 * v) * ld, lane_off)
-                                                                   : zero_el<T>();
+            const int n = jt * 16 + 4 * v + gl;
+            const T el = (ml_ok && n < rows_c && (!diag || ml >= n)) ? *at(Csc + (long) (16 * jt + 4 * v) * ld, lo)
+                                                                     : zero_el<T>();
             ure[jt][v] = re_of(el);
             uim[jt][v] = im_of(el);
           }
@@ -381,36 +398,43 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
           load_b(tile + (long) kCB * cc + (long) kCB * j * ld, ld, img_off, rows_c);
         }
         else {
-          // my own X_s is the column operand of the diagonal block: image [k][m] straight from the (negated)
+          // my own X_s is the column operand of the diagonal block: image [k][m] straight from the
           // operand registers, no trip through memory
+          R* bi = Bimg + gl * C::LD + ml;
 #pragma unroll
           for (int k4 = 0; k4 < 16; ++k4) {
-            Bimg[(4 * k4 + g) * C::LD + m] = -a_re[k4];
-            Bimg[C::IMG + (4 * k4 + g) * C::LD + m] = -a_im[k4];
+            bi[(4 * k4) * C::LD] = a_re[k4];
+            bi[C::IMG + (4 * k4) * C::LD] = a_im[k4];
           }
         }
         __syncthreads();
-        coop_mma64_rega<T>(a_re, a_im, Bimg, ure, uim);
+        coop_mma64_rega<T, true>(a_re, a_im, Bimg, ure, uim);
         const bool to_lds = diag && (j == s - 1);  // (see the real-type path: straight into the L planes)
-        if (to_lds)
+        if (to_lds) {
           __syncthreads();
+          R* Lre = lds + gl * kPDLd + ml;
+          R* Lim = Lre + kPD * kPDLd;
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
+          for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const int n = jt * 16 + 4 * v + g;
-            const bool in = (m_ok && n < rows_c && (!diag || m >= n));
-            if (to_lds) {
-              R* Lre = lds;
-              R* Lim = Lre + kPD * kPDLd;
-              Lre[n * kPDLd + m] = in ? ure[jt][v] : ((m == n && m >= rows_s) ? R(1) : R(0));
-              Lim[n * kPDLd + m] = (in && m != n) ? uim[jt][v] : R(0);
+            for (int v = 0; v < 4; ++v) {
+              const int n = jt * 16 + 4 * v + gl;
+              const bool in = (ml_ok && n < rows_c && ml >= n);
+              Lre[(jt * 16 + 4 * v) * kPDLd] = in ? ure[jt][v] : ((ml == n && ml >= rows_s) ? R(1) : R(0));
+              Lim[(jt * 16 + 4 * v) * kPDLd] = (in && ml != n) ? uim[jt][v] : R(0);
             }
-            else if (in) {
-              *at(Csc + (long) (16 * jt + 4 * v) * ld, lane_off) =
-                  make_el<T>(ure[jt][v], (diag && m == n) ? R(0) : uim[jt][v]);
+        }
+        else {
+#pragma unroll
+          for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const int n = jt * 16 + 4 * v + gl;
+              if (ml_ok && n < rows_c && (!diag || ml >= n))
+                *at(Csc + (long) (16 * jt + 4 * v) * ld, lo) =
+                    make_el<T>(ure[jt][v], (diag && ml == n) ? R(0) : uim[jt][v]);
             }
-          }
+        }
       }
       __syncthreads();  // the next step (or the diagonal phase) rewrites the image
       continue;
@@ -425,18 +449,25 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
     acc_t xre[4], xim[4];
     coop_mma64<T>(Aimg, Bimg, xre, xim);
     __syncthreads();  // every wave is done reading the A image before it is overwritten with X_s
+    {
+      int mx = wave * 16 + c, gx = g;
+      asm volatile("" : "+v"(mx), "+v"(gx));  // (addresses from the lane parts in place, not hoisted and spilled)
+      R* Ax = Aimg + Mma<R>::irow(gx, 0) * C::LD + mx;
+      T* Xg = Asj + mx + (long) Mma<R>::irow(gx, 0) * ld;
+      const bool mx_ok = mx < rows_s;
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
+      for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int m = wave * 16 + c, n = jt * 16 + Mma<R>::irow(g, v);
-        // X_s stays in LDS as the row operand of this step's updates: image [k = n][m]
-        Aimg[n * C::LD + m] = xre[jt][v];
-        if constexpr (C::CX)
-          Aimg[C::IMG + n * C::LD + m] = xim[jt][v];
-        if (m < rows_s)
-          store_wt(&Asj[m + (long) n * ld], make_el<T>(xre[jt][v], C::CX ? xim[jt][v] : R(0)));
-      }
+        for (int v = 0; v < 4; ++v) {
+          const int n0 = jt * 16 + Mma<R>::irow(0, v);
+          // X_s stays in LDS as the row operand of this step's updates: image [k = n][m]
+          Ax[n0 * C::LD] = xre[jt][v];
+          if constexpr (C::CX)
+            Ax[C::IMG + n0 * C::LD] = xim[jt][v];
+          if (mx_ok)
+            store_wt(&Xg[(long) n0 * ld], make_el<T>(xre[jt][v], C::CX ? xim[jt][v] : R(0)));
+        }
+    }
     coop_publish(&xflag[(long) j * G + s], 1u, false);
     // the updates below read X(c, j) of the strips j < c < s (my own X_s is in LDS)
     if (s - j - 1 > 0 && !coop_wait_all(&xflag[(long) j * G + j + 1], s - j - 1, &wait_slot, spin_limit)) {
@@ -468,13 +499,20 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
           coop_fetch<T>(nextB, tile + (long) kCB * (cc + 1) + (long) kCB * j * ld, ld, min(kCB, kb - kCB * (cc + 1)),
                         jb);
       T* Csc = tile + (long) kCB * s + (long) kCB * cc * ld;
+      // lane parts made opaque once per block (see the register-operand path): hoisted out of this loop the 16
+      // addresses and masks would be spilled
+      int ml = wave * 16 + c, gl = g;
+      asm volatile("" : "+v"(ml), "+v"(gl));
+      const bool ml_ok = ml < rows_s;
+      T* Cl = Csc + ml + (long) Mma<R>::irow(gl, 0) * ld;  // irow is linear: irow(g, v) = irow(g, 0) + irow(0, v)
       T cv[4][4];
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          const int m = wave * 16 + c, n = jt * 16 + Mma<R>::irow(g, v);
-          cv[jt][v] = (m < rows_s && n < rows_c && (!diag || m >= n)) ? Csc[m + (long) n * ld] : zero_el<T>();
+          const int n = jt * 16 + Mma<R>::irow(gl, v);
+          cv[jt][v] = (ml_ok && n < rows_c && (!diag || ml >= n)) ? Cl[(long) (jt * 16 + Mma<R>::irow(0, v)) * ld]
+                                                                  : zero_el<T>();
         }
       acc_t ure[4], uim[4];
       coop_mma64<T>(Aimg, diag ? Aimg : Bimg, ure, uim);
@@ -487,8 +525,8 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
       for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          const int m = wave * 16 + c, n = jt * 16 + Mma<R>::irow(g, v);
-          const bool in = (m < rows_s && n < rows_c && (!diag || m >= n));
+          const int m = ml, n = jt * 16 + Mma<R>::irow(gl, v);
+          const bool in = (ml_ok && n < rows_c && (!diag || m >= n));
           T r = cv[jt][v];
           if constexpr (C::CX) {
             r = T{r.re - ure[jt][v], (diag && m == n) ? R(0) : r.im - uim[jt][v]};
@@ -509,7 +547,7 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
             }
           }
           else if (in) {
-            Csc[m + (long) n * ld] = r;
+            Cl[(long) (jt * 16 + Mma<R>::irow(0, v)) * ld] = r;
           }
         }
       __syncthreads();  // B image is rewritten by the next iteration
