@@ -91,6 +91,8 @@ struct TrsmArgs {
   // upper != 0: X(il) = B(il) * U^-H with U = l upper triangular (the 64-column blocks are swept right to
   // left); winv block j then holds inv(U_jj) (upper triangle valid, rest zero)
   int upper = 0;
+  // != 0: the waves run at raised priority (a panel solve on the critical path beside the bulk update)
+  int prio = 0;
 };
 template <class T>
 void launch_trsm(const TrsmArgs<T>& args, hipStream_t stream);

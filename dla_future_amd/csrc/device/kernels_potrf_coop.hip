@@ -255,7 +255,7 @@ __device__ __forceinline__ void coop_mma64_rega(const real_t<T> (&a_re)[16], con
 template <class T>
 __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__ tile, int ld, int kb,
                                                                   T* __restrict__ winv, int* info, int info_base,
-                                                                  unsigned* sync, long spin_limit) {
+                                                                  unsigned* sync, long spin_limit, int prio) {
   using C = CoopCfg<T>;
   using R = real_t<T>;
   using acc_t = typename Mma<R>::acc_t;
@@ -276,6 +276,11 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
 
   if (*info != 0)
     return;
+  // The strips sit on compute units they share with waves of the bulk update (16 strips cannot own CUs of a device
+  // whose every CU holds persistent update workgroups): raised wave priority lets the SIMD's arbiter issue the
+  // strip's instructions first, the update waves fill the slots it leaves.
+  if (prio)
+    __builtin_amdgcn_s_setprio(3);
 
   R* Aimg = lds;
   R* Bimg = C::REGA ? lds : lds + C::NPL * C::IMG;
@@ -622,6 +627,15 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
   }
 }
 
+// DLAF_MI355X_POTRF_PRIO=0 leaves the strips at the default wave priority (A/B runs)
+static int coop_wave_prio() {
+  static const int p = [] {
+    const char* e = std::getenv("DLAF_MI355X_POTRF_PRIO");
+    return e ? std::atoi(e) : 1;
+  }();
+  return p;
+}
+
 static void fatal_device_config(const char* what) {
   std::fprintf(stderr, "[dlaf_mi355x] %s\n", what);
   std::abort();
@@ -640,7 +654,7 @@ void launch_potrf_coop(T* tile, int ld, int kb, T* winv, int* info, int info_bas
   if (!sync_is_zero)
     (void) hipMemsetAsync(sync, 0, sizeof(unsigned) * ((size_t) G + (size_t) G * G), stream);
   hipLaunchKernelGGL((potrf_coop_kernel<T>), dim3((unsigned) G), dim3(kThreads), CoopCfg<T>::LDS_BYTES, stream, tile, ld,
-                     kb, winv, info, info_base, sync, coop_spin_limit());
+                     kb, winv, info, info_base, sync, coop_spin_limit(), coop_wave_prio());
 }
 
 template <class T>

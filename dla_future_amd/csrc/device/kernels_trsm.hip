@@ -251,6 +251,8 @@ __global__ __launch_bounds__(kThreads, (TrsmRowsCfg<NW, ST>::WAVES_PER_SIMD)) vo
 
   if (*p.info != 0)
     return;
+  if (p.prio)
+    __builtin_amdgcn_s_setprio(2);
   const int il = p.il0 + blockIdx.x / spt;
   const int strip = blockIdx.x % spt;
   const int gi = il * p.pr + p.ri;

@@ -873,6 +873,12 @@ void DeviceMatrix<T>::factorize_async() {
     ta.winv = Wkk;
     ta.n = kb;
     ta.info = info;
+    // on the side stream the solve runs beside the bulk update and every later step waits for it
+    static const int trsm_prio = [] {
+      const char* e = std::getenv("DLAF_MI355X_TRSM_PRIO");
+      return e ? std::atoi(e) : 1;
+    }();
+    ta.prio = (ts != s_main) ? trsm_prio : 0;
     // algorithmic work: n^2 m flop and (n^2/2 + 2 m n) elements per tile
     double fl = 0, by = 0;
     for (long il = il0; il < il1; ++il) {
