@@ -122,6 +122,41 @@ SIGNATURES = {
     "dlaf_mi355x_bt_reduction_to_band_c": (_i, [_i, _i, _vp, DLAFDescriptor, _vp, DLAFDescriptor, _vp]),
     "dlaf_mi355x_bt_reduction_to_band_z": (_i, [_i, _i, _vp, DLAFDescriptor, _vp, DLAFDescriptor, _vp]),
     "dlaf_mi355x_bt_reduction_to_band_device": (_i, [_i, _vp, _vp, _vp]),
+    "dlaf_mi355x_band_to_tridiagonal_s": (_i, [_i, _vp, DLAFDescriptor, _i, _vp, _vp, _vp, _i]),
+    "dlaf_mi355x_bt_band_to_tridiagonal_s": (_i, [_i, _i, _i, _vp, _i, _vp, _i]),
+    "dlaf_mi355x_band_to_tridiagonal_d": (_i, [_i, _vp, DLAFDescriptor, _i, _vp, _vp, _vp, _i]),
+    "dlaf_mi355x_bt_band_to_tridiagonal_d": (_i, [_i, _i, _i, _vp, _i, _vp, _i]),
+    "dlaf_mi355x_band_to_tridiagonal_c": (_i, [_i, _vp, DLAFDescriptor, _i, _vp, _vp, _vp, _i]),
+    "dlaf_mi355x_bt_band_to_tridiagonal_c": (_i, [_i, _i, _i, _vp, _i, _vp, _i]),
+    "dlaf_mi355x_band_to_tridiagonal_z": (_i, [_i, _vp, DLAFDescriptor, _i, _vp, _vp, _vp, _i]),
+    "dlaf_mi355x_bt_band_to_tridiagonal_z": (_i, [_i, _i, _i, _vp, _i, _vp, _i]),
+    "dlaf_symmetric_eigensolver_s": (_i, [_i, _ch, _vp, DLAFDescriptor, _vp, _vp, DLAFDescriptor]),
+    "dlaf_symmetric_generalized_eigensolver_s": (_i, [_i, _ch, _vp, DLAFDescriptor, _vp, DLAFDescriptor, _vp, _vp, DLAFDescriptor]),
+    "dlaf_symmetric_generalized_eigensolver_factorized_s": (_i, [_i, _ch, _vp, DLAFDescriptor, _vp, DLAFDescriptor, _vp, _vp, DLAFDescriptor]),
+    "dlaf_symmetric_eigensolver_d": (_i, [_i, _ch, _vp, DLAFDescriptor, _vp, _vp, DLAFDescriptor]),
+    "dlaf_symmetric_generalized_eigensolver_d": (_i, [_i, _ch, _vp, DLAFDescriptor, _vp, DLAFDescriptor, _vp, _vp, DLAFDescriptor]),
+    "dlaf_symmetric_generalized_eigensolver_factorized_d": (_i, [_i, _ch, _vp, DLAFDescriptor, _vp, DLAFDescriptor, _vp, _vp, DLAFDescriptor]),
+    "dlaf_hermitian_eigensolver_c": (_i, [_i, _ch, _vp, DLAFDescriptor, _vp, _vp, DLAFDescriptor]),
+    "dlaf_hermitian_generalized_eigensolver_c": (_i, [_i, _ch, _vp, DLAFDescriptor, _vp, DLAFDescriptor, _vp, _vp, DLAFDescriptor]),
+    "dlaf_hermitian_generalized_eigensolver_factorized_c": (_i, [_i, _ch, _vp, DLAFDescriptor, _vp, DLAFDescriptor, _vp, _vp, DLAFDescriptor]),
+    "dlaf_hermitian_eigensolver_z": (_i, [_i, _ch, _vp, DLAFDescriptor, _vp, _vp, DLAFDescriptor]),
+    "dlaf_hermitian_generalized_eigensolver_z": (_i, [_i, _ch, _vp, DLAFDescriptor, _vp, DLAFDescriptor, _vp, _vp, DLAFDescriptor]),
+    "dlaf_hermitian_generalized_eigensolver_factorized_z": (_i, [_i, _ch, _vp, DLAFDescriptor, _vp, DLAFDescriptor, _vp, _vp, DLAFDescriptor]),
+    "dlaf_pssyevd": (None, [_ch, _i, _vp, _i, _i, _IP, _vp, _vp, _i, _i, _IP, _IP]),
+    "dlaf_pdsyevd": (None, [_ch, _i, _vp, _i, _i, _IP, _vp, _vp, _i, _i, _IP, _IP]),
+    "dlaf_pcheevd": (None, [_ch, _i, _vp, _i, _i, _IP, _vp, _vp, _i, _i, _IP, _IP]),
+    "dlaf_pzheevd": (None, [_ch, _i, _vp, _i, _i, _IP, _vp, _vp, _i, _i, _IP, _IP]),
+    "dlaf_pssygvd": (None, [_ch, _i, _vp, _i, _i, _IP, _vp, _i, _i, _IP, _vp, _vp, _i, _i, _IP, _IP]),
+    "dlaf_pssygvd_factorized": (None, [_ch, _i, _vp, _i, _i, _IP, _vp, _i, _i, _IP, _vp, _vp, _i, _i, _IP, _IP]),
+    "dlaf_pdsygvd": (None, [_ch, _i, _vp, _i, _i, _IP, _vp, _i, _i, _IP, _vp, _vp, _i, _i, _IP, _IP]),
+    "dlaf_pdsygvd_factorized": (None, [_ch, _i, _vp, _i, _i, _IP, _vp, _i, _i, _IP, _vp, _vp, _i, _i, _IP, _IP]),
+    "dlaf_pchegvd": (None, [_ch, _i, _vp, _i, _i, _IP, _vp, _i, _i, _IP, _vp, _vp, _i, _i, _IP, _IP]),
+    "dlaf_pchegvd_factorized": (None, [_ch, _i, _vp, _i, _i, _IP, _vp, _i, _i, _IP, _vp, _vp, _i, _i, _IP, _IP]),
+    "dlaf_pzhegvd": (None, [_ch, _i, _vp, _i, _i, _IP, _vp, _i, _i, _IP, _vp, _vp, _i, _i, _IP, _IP]),
+    "dlaf_pzhegvd_factorized": (None, [_ch, _i, _vp, _i, _i, _IP, _vp, _i, _i, _IP, _vp, _vp, _i, _i, _IP, _IP]),
+    "dlaf_mi355x_tridiagonal_eigensolver_s": (_i, [_i, _i, _vp, _vp, _vp, _vp, _i]),
+    "dlaf_mi355x_tridiagonal_eigensolver_d": (_i, [_i, _i, _vp, _vp, _vp, _vp, _i]),
+    "dlaf_mi355x_eigensolver_profile": (_i, [C.POINTER(C.c_double)]),
     "dlaf_mi355x_get_band_size": (_i, [_i]),
     "dlaf_mi355x_red2band_profile": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dlaf_mi355x_set_random_hpd": (_i, [_i, _ch, _vp, DLAFDescriptor, _i]),

@@ -34,6 +34,9 @@ struct GemmArgs {
   T alpha{}, beta{};
   int ksplit = 1;
   T* partial = nullptr;
+  // strided batch (ksplit == 1 only): product q of [0, batch) takes a + q * sa, b + q * sb, c + q * sc
+  int batch = 1;
+  long sa = 0, sb = 0, sc = 0;
 };
 template <class T>
 void launch_gemm(const GemmArgs<T>& args, hipStream_t stream);
@@ -117,7 +120,8 @@ void launch_make_v(const T* qt, int b, int nr, long e0, long r0, long n, T* v, l
 // T factor of a block of k reflectors from S = V^H V (k x k, lds) and taus (t_factor_impl.h:60-131); t: k x k, ldt,
 // upper triangular, the strict lower part set to zero
 template <class T>
-void launch_tfactor(const T* s, long lds_, const T* taus, int k, T* t, long ldt, hipStream_t stream);
+void launch_tfactor(const T* s, long lds_, const T* taus, int k, T* t, long ldt, hipStream_t stream, int batch = 1,
+                    long bs = 0, long btau = 0, long bt = 0);  // strided batch: problem q at s + q bs, taus + q btau, t + q bt
 // zero rows [0, nrows) x ncols of a column-major array
 template <class T>
 void launch_zero_rows(T* x, long ldx, long nrows, int ncols, hipStream_t stream);

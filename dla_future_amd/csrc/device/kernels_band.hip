@@ -90,6 +90,11 @@ __global__ __launch_bounds__(GenCfg<T>::type::THREADS, 2) void gemm_kernel(GemmA
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   R* lds = reinterpret_cast<R*>(lds_raw);
   const int bid = blockIdx.x;
+  if (p.batch > 1) {
+    p.a += (long) blockIdx.y * p.sa;
+    p.b += (long) blockIdx.y * p.sb;
+    p.c += (long) blockIdx.y * p.sc;
+  }
   const int ks = bid / (mp.MB * mp.NB);
   const int rem = bid % (mp.MB * mp.NB);
   const int bm = rem % mp.MB, bn = rem / mp.MB;
@@ -486,8 +491,12 @@ __device__ __forceinline__ T wave_sum(T v) {
 }
 
 template <class T>
-__global__ __launch_bounds__(kThreads) void tfactor_kernel(const T* s, long lds_, const T* taus, int k, T* t, long ldt) {
+__global__ __launch_bounds__(kThreads) void tfactor_kernel(const T* s, long lds_, const T* taus, int k, T* t, long ldt,
+                                                           long bs, long btau, long bt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tf_raw[];
+  s += (long) blockIdx.y * bs;  // strided batch
+  taus += (long) blockIdx.y * btau;
+  t += (long) blockIdx.y * bt;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = blockIdx.x * (kThreads / 64) + wave;
   if (i >= k)
@@ -911,7 +920,7 @@ void launch_gemm(const GemmArgs<T>& a, hipStream_t stream) {
   GemmMap mp;
   mp.MB = (a.M + Cfg::BM - 1) / Cfg::BM;
   mp.NB = (a.N + Cfg::BN - 1) / Cfg::BN;
-  mp.KS = (a.ksplit > 1 && a.partial != nullptr && a.K > 0) ? a.ksplit : 1;
+  mp.KS = (a.ksplit > 1 && a.partial != nullptr && a.K > 0 && a.batch <= 1) ? a.ksplit : 1;
   int kchunk = (a.K + mp.KS - 1) / mp.KS;
   kchunk = ((kchunk + Cfg::BK - 1) / Cfg::BK) * Cfg::BK;
   if (kchunk <= 0)
@@ -919,8 +928,8 @@ void launch_gemm(const GemmArgs<T>& a, hipStream_t stream) {
   mp.kchunk = kchunk;
   if (mp.KS > 1)
     mp.KS = (a.K + kchunk - 1) / kchunk;
-  hipLaunchKernelGGL((gemm_kernel<T>), dim3((unsigned) (mp.MB * mp.NB * mp.KS)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream,
-                     a, mp);
+  hipLaunchKernelGGL((gemm_kernel<T>), dim3((unsigned) (mp.MB * mp.NB * mp.KS), (unsigned) std::max(a.batch, 1)),
+                     dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, a, mp);
   if (mp.KS > 1)
     hipLaunchKernelGGL((gemm_reduce_kernel<T>), dim3((unsigned) ((Cfg::BM * Cfg::BN + kThreads - 1) / kThreads), (unsigned) (mp.MB * mp.NB)),
                        dim3(kThreads), 0, stream, a, mp);
@@ -1146,16 +1155,17 @@ void launch_make_v(const T* qt, int b, int nr, long e0, long r0, long n, T* v, l
 }
 
 template <class T>
-void launch_tfactor(const T* s, long lds_, const T* taus, int k, T* t, long ldt, hipStream_t stream) {
-  if (k <= 0)
+void launch_tfactor(const T* s, long lds_, const T* taus, int k, T* t, long ldt, hipStream_t stream, int batch, long bs,
+                    long btau, long bt) {
+  if (k <= 0 || batch <= 0)
     return;
   if (k > kTfMax) {
     fprintf(stderr, "[dlaf_mi355x] T factor: %d reflectors exceed the supported %d\n", k, kTfMax);
     abort();
   }
   const int rows_per_wg = kThreads / 64;
-  hipLaunchKernelGGL((tfactor_kernel<T>), dim3((unsigned) ((k + rows_per_wg - 1) / rows_per_wg)), dim3(kThreads),
-                     (size_t) rows_per_wg * k * sizeof(T), stream, s, lds_, taus, k, t, ldt);
+  hipLaunchKernelGGL((tfactor_kernel<T>), dim3((unsigned) ((k + rows_per_wg - 1) / rows_per_wg), (unsigned) batch),
+                     dim3(kThreads), (size_t) rows_per_wg * k * sizeof(T), stream, s, lds_, taus, k, t, ldt, bs, btau, bt);
 }
 
 template <class T>
@@ -1204,7 +1214,7 @@ void band_kernels_init() {
   template void launch_panel_move<T>(T*, long, int, int, int, int, int, int, int, int, int, int, T*, long, long, bool, \
                                      hipStream_t);                                                                     \
   template void launch_make_v<T>(const T*, int, int, long, long, long, T*, long, hipStream_t);                         \
-  template void launch_tfactor<T>(const T*, long, const T*, int, T*, long, hipStream_t);                               \
+  template void launch_tfactor<T>(const T*, long, const T*, int, T*, long, hipStream_t, int, long, long, long);        \
   template void launch_zero_rows<T>(T*, long, long, int, hipStream_t);
 INST(float)
 INST(double)

@@ -1,0 +1,656 @@
+// kernels_tridiag.hip -- gfx950 kernels of the second eigensolver stage: Hermitian band matrix -> real symmetric
+// tridiagonal matrix by bulge chasing, and the helpers of the matching back-transformation (SURVEY.md section 8(f)
+// item 4).
+//
+// Reference: eigensolver/band_to_tridiag/mc.h -- SweepWorker::start_sweep / do_step (:503-531) on the compact band
+// copy BandBlock (:180-206), one CPU task per step, dependencies between consecutive sweeps through counting
+// semaphores (:683-709, :760-773); the reference's GPU backend copies the band to the host and runs the same CPU
+// code.  bt_band_to_tridiag/impl.h:139-175 (computeVT) for the well-formed reflector blocks.
+//
+// MI355X design: ONE launch.  Persistent workgroups draw sweeps from a counter (so a workgroup only ever waits for
+// a sweep that some resident workgroup already owns: no co-residency assumption), sweep s runs step t once sweep
+// s - 1 has published t + 2 finished steps.  A step touches 1.5 b^2 elements of the band copy, which stays in the
+// memory-side cache (42 MB at n = 20480, b = 128); the band bytes are handed from workgroup to workgroup, possibly on
+// another XCD, once per sweep: they are stored write-through and loaded sc1 (cdna_hip_programming.md, Guideline 16:
+// "every load sc1"), the progress word of a sweep is one relaxed agent-scope atomic.  Inside a step a wave owns a
+// column of the block (rows on lanes: 512-byte contiguous loads), the matrix-vector products of the two-sided update
+// accumulate per wave in LDS and are summed once.
+#include <cstdio>
+#include <cstdlib>
+
+#include "device_api.hpp"
+#include "tridiag_api.hpp"
+
+namespace dlaf_mi355x {
+
+namespace {
+
+constexpr int kB2tThreads = 512;
+constexpr int kB2tWaves = kB2tThreads / 64;
+constexpr int kB2tMaxBand = 256;
+constexpr int kB2tRegs = kB2tMaxBand / 64;  // elements of a column part one lane holds
+constexpr unsigned kB2tDone = 0x7fffffffu;
+constexpr long kB2tSpinLimit = 40000000;
+
+template <class T>
+__device__ __forceinline__ T c_mul(const T& a, const T& b) {
+  if constexpr (TypeInfo<T>::is_complex)
+    return T{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+  else
+    return a * b;
+}
+// conj(a) * b
+template <class T>
+__device__ __forceinline__ T c_cmul(const T& a, const T& b) {
+  if constexpr (TypeInfo<T>::is_complex)
+    return T{a.re * b.re + a.im * b.im, a.re * b.im - a.im * b.re};
+  else
+    return a * b;
+}
+template <class T>
+__device__ __forceinline__ T c_add(const T& a, const T& b) {
+  if constexpr (TypeInfo<T>::is_complex)
+    return T{a.re + b.re, a.im + b.im};
+  else
+    return a + b;
+}
+template <class T>
+__device__ __forceinline__ T c_sub(const T& a, const T& b) {
+  if constexpr (TypeInfo<T>::is_complex)
+    return T{a.re - b.re, a.im - b.im};
+  else
+    return a - b;
+}
+template <class T>
+__device__ __forceinline__ T c_conj(const T& a) {
+  if constexpr (TypeInfo<T>::is_complex)
+    return T{a.re, -a.im};
+  else
+    return a;
+}
+template <class T>
+__device__ __forceinline__ T c_scale(const T& a, real_t<T> s) {
+  return make_el<T>(re_of(a) * s, im_of(a) * s);
+}
+template <class T>
+__device__ __forceinline__ real_t<T> c_abs2(const T& a) {
+  return re_of(a) * re_of(a) + im_of(a) * im_of(a);
+}
+
+template <class T>
+__device__ __forceinline__ T wave_sum_t(T v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    if constexpr (TypeInfo<T>::is_complex) {
+      v.re += __shfl_xor(v.re, off);
+      v.im += __shfl_xor(v.im, off);
+    }
+    else
+      v += __shfl_xor(v, off);
+  }
+  return v;
+}
+
+// write-through store / sc1 load of one element (relaxed agent-scope atomics on its 4- or 8-byte words)
+template <class T>
+__device__ __forceinline__ void st_wt(T* p, const T& v) {
+  if constexpr (sizeof(T) == 4) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  }
+  else if constexpr (sizeof(T) == 8) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  else {
+    struct Two {
+      unsigned long long a, b;
+    };
+    const Two t = __builtin_bit_cast(Two, v);
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+    __hip_atomic_store(q, t.a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, t.b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+template <class T>
+__device__ __forceinline__ T ld_sc(const T* p) {
+  if constexpr (sizeof(T) == 4) {
+    return __builtin_bit_cast(T, __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT));
+  }
+  else if constexpr (sizeof(T) == 8) {
+    return __builtin_bit_cast(T, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT));
+  }
+  else {
+    struct Two {
+      unsigned long long a, b;
+    };
+    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+    Two t;
+    t.a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t.b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __builtin_bit_cast(T, t);
+  }
+}
+
+// ======================================================================================= band copy
+template <class T>
+__global__ __launch_bounds__(kThreads) void band_extract_kernel(const T* tiles, long ltr, int nb, int pr, int ri, int pc,
+                                                                int ci, long n, int b, T* band) {
+  const int ldb = 2 * b;
+  const long total = n * ldb;
+  for (long e = (long) blockIdx.x * kThreads + threadIdx.x; e < total; e += (long) gridDim.x * kThreads) {
+    const long c = e / ldb;
+    const int o = (int) (e % ldb);
+    const long r = c + o;
+    T v = zero_el<T>();
+    if (o <= b && r < n) {
+      const long gi = r / nb, gj = c / nb;
+      if (gi % pr == ri && gj % pc == ci) {
+        const long il = gi / pr, jl = gj / pc;
+        v = tiles[(il + jl * ltr) * (long) nb * nb + (r % nb) + (c % nb) * (long) nb];
+        if (o == 0)
+          v = make_el<T>(re_of(v), real_t<T>(0));
+      }
+    }
+    band[e] = v;
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(kThreads) void tridiag_extract_kernel(const T* band, long n, int b, real_t<T>* d,
+                                                                   real_t<T>* e) {
+  const long i = (long) blockIdx.x * kThreads + threadIdx.x;
+  if (i < n) {
+    d[i] = re_of(band[i * 2 * b]);
+    e[i] = (i + 1 < n) ? re_of(band[i * 2 * b + 1]) : real_t<T>(0);
+  }
+}
+
+// ======================================================================================= bulge chasing
+template <class T>
+struct B2tArgs {
+  T* band;
+  long n;
+  int b;
+  T* vout;
+  long ldv;
+  unsigned* progress;  // one word per sweep: finished steps (kB2tDone when the sweep is over)
+  unsigned* next;      // the sweep counter
+  unsigned* failed;    // != 0: some workgroup gave up a wait
+  int nsweeps;
+  int* info;
+  long spin_limit;
+};
+
+// LDS image of a workgroup (elements of T): v, w, zb, cs, vnew (b each), the per-wave partial products (waves x 2 b),
+// then a few scalars
+template <class T>
+struct B2tLds {
+  T* v;
+  T* w;
+  T* zb;
+  T* cs;
+  T* vnew;
+  T* zw;
+  T* sc;  // [0] tau, [1] tau of the new reflector, [2] alpha
+  unsigned* slot;
+  __device__ B2tLds(unsigned char* raw, int b) {
+    T* p = reinterpret_cast<T*>(raw);
+    v = p;
+    w = v + b;
+    zb = w + b;
+    cs = zb + b;
+    vnew = cs + b;
+    zw = vnew + b;
+    sc = zw + (size_t) kB2tWaves * 2 * b;
+    slot = reinterpret_cast<unsigned*>(sc + 4);
+  }
+};
+template <class T>
+size_t b2t_lds_bytes(int b) {
+  return ((size_t) 5 * b + (size_t) kB2tWaves * 2 * b + 4) * sizeof(T) + 16;
+}
+
+// xLARFG of x[0 .. len) held in LDS (one wave): on return x[0] = 1 and x[1 ..] = the reflector, *tau and *beta set.
+// (HH_reflector, mc.h:55-68.)
+template <class T>
+__device__ __forceinline__ void wave_larfg(T* x, int len, int lane, T& tau, T& beta) {
+  using R = real_t<T>;
+  R ss = R(0);
+  for (int i = 1 + lane; i < len; i += 64)
+    ss += c_abs2(x[i]);
+  ss = wave_sum_t(ss);
+  const T alpha = x[0];
+  const R ar = re_of(alpha), ai = im_of(alpha);
+  if (ss == R(0) && ai == R(0)) {
+    tau = zero_el<T>();
+    beta = alpha;
+  }
+  else {
+    const R nrm = sqrt(ar * ar + ai * ai + ss);
+    const R bt = ar >= R(0) ? -nrm : nrm;
+    tau = make_el<T>((bt - ar) / bt, -ai / bt);
+    // 1 / (alpha - beta)
+    const R dr = ar - bt, di = ai;
+    const R dd = dr * dr + di * di;
+    const T scale = make_el<T>(dr / dd, -di / dd);
+    for (int i = 1 + lane; i < len; i += 64)
+      x[i] = c_mul(x[i], scale);
+    beta = make_el<T>(bt, R(0));
+  }
+  if (lane == 0)
+    x[0] = make_el<T>(R(1), R(0));
+}
+
+template <class T>
+__global__ __launch_bounds__(kB2tThreads) void b2t_kernel(B2tArgs<T> p) {
+  using R = real_t<T>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char b2t_raw[];
+  B2tLds<T> L(b2t_raw, p.b);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = p.b, ldb = 2 * b;
+  const long n = p.n;
+  T* zw = L.zw + (size_t) wave * 2 * b;
+
+  for (;;) {
+    if (tid == 0)
+      *L.slot = __hip_atomic_fetch_add(p.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const long s = (long) *L.slot;
+    __syncthreads();
+    if (s >= p.nsweeps)
+      break;
+    // all threads: wait until sweep s - 1 has finished `need` steps
+    auto wait_prev = [&](unsigned need) -> bool {
+      if (s == 0) {
+        __syncthreads();
+        return true;
+      }
+      if (tid == 0) {
+        unsigned v;
+        long spins = 0;
+        while ((v = __hip_atomic_load(p.progress + (s - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > p.spin_limit ||
+              ((spins & 255) == 0 && __hip_atomic_load(p.failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+            v = 0xFFFFFFFFu;
+            break;
+          }
+        }
+        *L.slot = v;
+      }
+      __syncthreads();
+      const unsigned r = *L.slot;
+      __syncthreads();
+      // (every load of band bytes below is an sc1 load: no agent-scope acquire needed, only program order)
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      return r != 0xFFFFFFFFu;
+    };
+    auto publish = [&](unsigned value) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0)
+        __hip_atomic_store(p.progress + s, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    bool ok = wait_prev(1u);
+    // ---- start_sweep: the reflector that annihilates column s below the first sub-diagonal -----------------------
+    const bool cx_last = TypeInfo<T>::is_complex && s == n - 2;
+    const int nsteps = cx_last ? 1 : (int) ((n - s - 2 + b - 1) / b);
+    if (ok) {
+      const int nn = (int) (n - s - 1 < b ? n - s - 1 : b);
+      T* col = p.band + s * ldb + 1;
+      for (int i = tid; i < nn; i += kB2tThreads)
+        L.v[i] = ld_sc(col + i);
+      __syncthreads();
+      if (wave == 0) {
+        T tau, beta;
+        wave_larfg(L.v, nn, lane, tau, beta);
+        if (lane == 0)
+          L.sc[0] = tau;
+        for (int i = lane; i < nn; i += 64)
+          st_wt(col + i, i == 0 ? beta : zero_el<T>());
+      }
+      __syncthreads();
+    }
+    for (int step = 0; step < nsteps && ok; ++step) {
+      const long j = 1 + s + (long) step * b;
+      const int nh = (int) (n - j < b ? n - j : b);
+      const long mrem = n - b - j;
+      const int m = (int) (mrem < 0 ? 0 : (mrem < b ? mrem : b));
+      const T tau = L.sc[0];
+      // compact copy of the reflector (compact_copy_to_tile, mc.h:492-497)
+      {
+        const long pos = (s / b + step) * (long) b;
+        T* dst = p.vout + pos + s * p.ldv;
+        for (int i = tid; i < nh; i += kB2tThreads)
+          dst[i] = i == 0 ? tau : L.v[i];
+      }
+      for (int i = tid; i < kB2tWaves * 2 * b; i += kB2tThreads)
+        L.zw[i] = zero_el<T>();
+      ok = wait_prev((unsigned) step + 2u);
+      if (!ok)
+        break;
+      const int rows = nh + m;
+      // ---- P1: z = A v over the rows of both blocks, cs = strictly-lower(A)^H v over the diagonal block -----------
+      for (int cc = wave; cc < nh; cc += kB2tWaves) {
+        const T vc = L.v[cc];
+        const T* col = p.band + (j + cc) * ldb;
+        T part = zero_el<T>();
+        for (int o = lane; o < rows - cc; o += 64) {
+          T a = ld_sc(col + o);
+          const int r = cc + o;
+          if (o == 0)
+            a = make_el<T>(re_of(a), R(0));
+          zw[r] = c_add(zw[r], c_mul(a, vc));
+          if (o > 0 && r < nh)
+            part = c_add(part, c_cmul(a, L.v[r]));
+        }
+        part = wave_sum_t(part);
+        if (lane == 0)
+          L.cs[cc] = part;
+      }
+      __syncthreads();
+      // ---- P2: w = tau (z + cs) - 1/2 tau (w^H v) v  (apply_HH_left_right_herm, mc.h:70-86);  zb = B v -----------
+      for (int r = tid; r < rows; r += kB2tThreads) {
+        T sum = zero_el<T>();
+#pragma unroll
+        for (int q = 0; q < kB2tWaves; ++q)
+          sum = c_add(sum, L.zw[(size_t) q * 2 * b + r]);
+        if (r < nh)
+          L.w[r] = c_mul(tau, c_add(sum, L.cs[r]));
+        else
+          L.zb[r - nh] = sum;
+      }
+      __syncthreads();
+      if (wave == 0) {
+        T dot = zero_el<T>();
+        for (int r = lane; r < nh; r += 64)
+          dot = c_add(dot, c_cmul(L.w[r], L.v[r]));
+        dot = wave_sum_t(dot);
+        if (lane == 0)
+          L.sc[2] = c_scale(c_mul(dot, tau), R(-0.5));
+      }
+      __syncthreads();
+      {
+        const T alpha = L.sc[2];
+        for (int r = tid; r < nh; r += kB2tThreads)
+          L.w[r] = c_add(L.w[r], c_mul(alpha, L.v[r]));
+      }
+      __syncthreads();
+      // ---- P3: D -= w v^H + v w^H (lower part, real diagonal) -------------------------------------------------------
+      for (int cc = wave; cc < nh; cc += kB2tWaves) {
+        T* col = p.band + (j + cc) * ldb;
+        const T vcc = c_conj(L.v[cc]), wcc = c_conj(L.w[cc]);
+        for (int o = lane; o < nh - cc; o += 64) {
+          const int r = cc + o;
+          T a = ld_sc(col + o);
+          if (o == 0)
+            a = make_el<T>(re_of(a) - R(2) * re_of(c_mul(L.w[r], vcc)), R(0));
+          else
+            a = c_sub(a, c_add(c_mul(L.w[r], vcc), c_mul(L.v[r], wcc)));
+          st_wt(col + o, a);
+        }
+      }
+      // ---- P4: first column of B after B -= tau (B v) v^H (apply_HH_right), then its reflector ------------------------
+      if (m > 0 && wave == 0) {
+        T* col = p.band + j * ldb + nh;
+        const T vcc = c_conj(L.v[0]);
+        for (int r = lane; r < m; r += 64)
+          L.vnew[r] = c_sub(ld_sc(col + r), c_mul(tau, c_mul(L.zb[r], vcc)));
+        if (m > 1) {
+          T tau2, beta;
+          wave_larfg(L.vnew, m, lane, tau2, beta);
+          if (lane == 0)
+            L.sc[1] = tau2;
+          for (int r = lane; r < m; r += 64)
+            st_wt(col + r, r == 0 ? beta : zero_el<T>());
+        }
+        else if (lane == 0) {
+          st_wt(col, L.vnew[0]);
+        }
+      }
+      __syncthreads();
+      // ---- P5/6: the other columns of B: right update, then (I - conj(tau2) v2 v2^H) from the left --------------------
+      if (m > 0) {
+        const T ctau2 = m > 1 ? c_conj(L.sc[1]) : zero_el<T>();
+        for (int cc = 1 + wave; cc < nh; cc += kB2tWaves) {
+          T* col = p.band + (j + cc) * ldb + (nh - cc);
+          const T tv = c_mul(tau, c_conj(L.v[cc]));
+          T a[kB2tRegs];
+          T part = zero_el<T>();
+#pragma unroll
+          for (int q = 0; q < kB2tRegs; ++q) {
+            const int r = lane + 64 * q;
+            if (r < m) {
+              a[q] = c_sub(ld_sc(col + r), c_mul(L.zb[r], tv));
+              part = c_add(part, c_cmul(a[q], L.vnew[r]));
+            }
+          }
+          if (m > 1) {
+            part = wave_sum_t(part);  // w3 = (column)^H v2
+            const T f = c_mul(ctau2, c_conj(part));
+#pragma unroll
+            for (int q = 0; q < kB2tRegs; ++q) {
+              const int r = lane + 64 * q;
+              if (r < m)
+                a[q] = c_sub(a[q], c_mul(L.vnew[r], f));
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < kB2tRegs; ++q) {
+            const int r = lane + 64 * q;
+            if (r < m)
+              st_wt(col + r, a[q]);
+          }
+        }
+      }
+      __syncthreads();
+      if (m > 1) {
+        for (int r = tid; r < m; r += kB2tThreads)
+          L.v[r] = L.vnew[r];
+        if (tid == 0)
+          L.sc[0] = L.sc[1];
+      }
+      publish((unsigned) step + 1u);
+      __syncthreads();
+    }
+    if (!ok) {
+      if (tid == 0) {
+        __hip_atomic_store(p.failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicCAS(p.info, 0, kInfoSchedulingFailure);
+      }
+    }
+    publish(kB2tDone);
+    __syncthreads();
+  }
+}
+
+// ======================================================================================= reflector blocks
+// one workgroup per block (ib, jb): well-formed 2 b x b image + taus
+template <class T>
+__global__ __launch_bounds__(kThreads) void b2t_expand_kernel(const T* vout, long ldv, long n, int b, int nblk, T* vx,
+                                                              T* taus) {
+  using R = real_t<T>;
+  const int ib = blockIdx.x, jb = blockIdx.y;
+  const long blk = (long) jb * nblk + ib;
+  T* out = vx + blk * 2 * (long) b * b;
+  T* tout = taus + blk * b;
+  if (ib < jb) {
+    return;  // (never read)
+  }
+  const int st = ib - jb;
+  const long nsweeps = TypeInfo<T>::is_complex ? n - 1 : n - 2;
+  for (int e = threadIdx.x; e < 2 * b * b; e += kThreads) {
+    const int r = e % (2 * b), k = e / (2 * b);
+    const long sw = (long) jb * b + k;
+    T v = zero_el<T>();
+    if (sw < nsweeps) {
+      const bool cx_last = TypeInfo<T>::is_complex && sw == n - 2;
+      const long nsteps = cx_last ? 1 : (n - sw - 2 + b - 1) / b;
+      if (st < nsteps) {
+        const long first = 1 + sw + (long) st * b;
+        const long len = n - first < b ? n - first : b;
+        const int i = r - k;
+        if (i == 0)
+          v = make_el<T>(R(1), R(0));
+        else if (i > 0 && i < len)
+          v = vout[(long) ib * b + i + sw * ldv];
+      }
+    }
+    out[e] = v;
+  }
+  for (int k = threadIdx.x; k < b; k += kThreads) {
+    const long sw = (long) jb * b + k;
+    T t = zero_el<T>();
+    if (sw < nsweeps) {
+      const bool cx_last = TypeInfo<T>::is_complex && sw == n - 2;
+      const long nsteps = cx_last ? 1 : (n - sw - 2 + b - 1) / b;
+      if (st < nsteps)
+        t = vout[(long) ib * b + sw * ldv];
+    }
+    tout[k] = t;
+  }
+}
+
+// e[r + cl * lde] = z[r + gc * ldz] for the local columns cl of a block-cyclic column axis (gc its global column),
+// real -> T on the way (castToComplex, tridiag_solver/impl.h:264-277)
+template <class R, class T>
+__global__ __launch_bounds__(kThreads) void cols_gather_cast_kernel(const R* z, long ldz, long n, int nb, int pc, int ci,
+                                                                    long ncols_loc, T* e, long lde) {
+  for (long cl = blockIdx.y; cl < ncols_loc; cl += gridDim.y) {
+    const long gc = ((cl / nb) * pc + ci) * nb + cl % nb;
+    for (long r = (long) blockIdx.x * kThreads + threadIdx.x; r < n; r += (long) gridDim.x * kThreads)
+      e[r + cl * lde] = make_el<T>((real_t<T>) z[r + gc * ldz], real_t<T>(0));
+  }
+}
+
+// tile (il, jl) of a tile-layout matrix <- rows gi nb .. of e (all rows of the local columns): gi = il * pr + ri
+template <class T>
+__global__ __launch_bounds__(kThreads) void rows_to_tiles_kernel(const T* e, long lde, long n, long ncols_loc, int nb,
+                                                                 int pr, int ri, long ltr, T* tiles) {
+  const long il = blockIdx.y, jl = blockIdx.z;
+  const long gi = il * pr + ri;
+  const long r0 = gi * nb;
+  const int rows = (int) (n - r0 < nb ? n - r0 : nb);
+  const int cols = (int) (ncols_loc - jl * nb < nb ? ncols_loc - jl * nb : nb);
+  T* t = tiles + (il + jl * ltr) * (long) nb * nb;
+  for (int idx = blockIdx.x * kThreads + threadIdx.x; idx < rows * cols; idx += gridDim.x * kThreads) {
+    const int r = idx % rows, c = idx / rows;
+    t[r + (long) c * nb] = e[(r0 + r) + (jl * nb + c) * lde];
+  }
+}
+
+}  // namespace
+
+template <class R, class T>
+void launch_cols_gather_cast(const R* z, long ldz, long n, int nb, int pc, int ci, long ncols_loc, T* e, long lde,
+                             hipStream_t stream) {
+  if (n <= 0 || ncols_loc <= 0)
+    return;
+  hipLaunchKernelGGL((cols_gather_cast_kernel<R, T>), dim3((unsigned) std::min<long>(8, (n + kThreads - 1) / kThreads),
+                                                           (unsigned) std::min<long>(ncols_loc, 8192)),
+                     dim3(kThreads), 0, stream, z, ldz, n, nb, pc, ci, ncols_loc, e, lde);
+}
+template <class T>
+void launch_rows_to_tiles(const T* e, long lde, long n, long ncols_loc, int nb, int pr, int ri, long ltr, long ltc, T* tiles,
+                          hipStream_t stream) {
+  if (ltr <= 0 || ltc <= 0)
+    return;
+  hipLaunchKernelGGL((rows_to_tiles_kernel<T>), dim3(8, (unsigned) ltr, (unsigned) ltc), dim3(kThreads), 0, stream, e, lde, n,
+                     ncols_loc, nb, pr, ri, ltr, tiles);
+}
+template void launch_cols_gather_cast<float, float>(const float*, long, long, int, int, int, long, float*, long, hipStream_t);
+template void launch_cols_gather_cast<double, double>(const double*, long, long, int, int, int, long, double*, long, hipStream_t);
+template void launch_cols_gather_cast<float, cfloat>(const float*, long, long, int, int, int, long, cfloat*, long, hipStream_t);
+template void launch_cols_gather_cast<double, cdouble>(const double*, long, long, int, int, int, long, cdouble*, long, hipStream_t);
+
+int b2t_max_band() {
+  return kB2tMaxBand;
+}
+
+template <class T>
+void launch_band_extract(const T* tiles, long ltr, int nb, int pr, int ri, int pc, int ci, long n, int b, T* band,
+                         hipStream_t stream) {
+  const long total = n * 2 * b;
+  if (total <= 0)
+    return;
+  const unsigned g = (unsigned) std::min<long>((total + kThreads - 1) / kThreads, 4096);
+  hipLaunchKernelGGL((band_extract_kernel<T>), dim3(g), dim3(kThreads), 0, stream, tiles, ltr, nb, pr, ri, pc, ci, n, b, band);
+}
+
+template <class T>
+void launch_tridiag_extract(const T* band, long n, int b, real_t<T>* d, real_t<T>* e, hipStream_t stream) {
+  if (n <= 0)
+    return;
+  hipLaunchKernelGGL((tridiag_extract_kernel<T>), dim3((unsigned) ((n + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                     stream, band, n, b, d, e);
+}
+
+template <class T>
+void launch_band_to_tridiag(T* band, long n, int b, T* vout, long ldv, unsigned* sync, int* info, hipStream_t stream) {
+  const long nsweeps = TypeInfo<T>::is_complex ? n - 1 : n - 2;
+  if (nsweeps <= 0)
+    return;
+  if (b > kB2tMaxBand || b < 1) {
+    fprintf(stderr, "[dlaf_mi355x] band_to_tridiagonal: band size %d outside the supported 1 .. %d\n", b, kB2tMaxBand);
+    abort();
+  }
+  static const long spin_limit = [] {
+    const char* e = std::getenv("DLAF_MI355X_B2T_SPIN_LIMIT");
+    return e ? std::atol(e) : kB2tSpinLimit;
+  }();
+  static const int max_wg = [] {
+    const char* e = std::getenv("DLAF_MI355X_B2T_WORKGROUPS");
+    return e ? std::max(1, std::atoi(e)) : 256;
+  }();
+  (void) hipMemsetAsync(sync, 0, b2t_sync_words(n) * sizeof(unsigned), stream);
+  B2tArgs<T> a;
+  a.band = band;
+  a.n = n;
+  a.b = b;
+  a.vout = vout;
+  a.ldv = ldv;
+  a.progress = sync + 64;
+  a.next = sync;
+  a.failed = sync + 16;
+  a.nsweeps = (int) nsweeps;
+  a.info = info;
+  a.spin_limit = spin_limit;
+  // sweeps that can be in flight together: one every two steps of the longest sweep
+  const long useful = std::max<long>(1, (n / b + 2) / 2 + 1);
+  const unsigned g = (unsigned) std::min<long>(std::min<long>(max_wg, nsweeps), useful);
+  const size_t lds = b2t_lds_bytes<T>(b);
+  static bool attr_set[4] = {false, false, false, false};
+  const int ti = TypeInfo<T>::is_complex ? (sizeof(T) == 16 ? 3 : 2) : (sizeof(T) == 8 ? 1 : 0);
+  if (!attr_set[ti]) {
+    (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&b2t_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int) b2t_lds_bytes<T>(kB2tMaxBand));
+    attr_set[ti] = true;
+  }
+  hipLaunchKernelGGL((b2t_kernel<T>), dim3(g), dim3(kB2tThreads), lds, stream, a);
+}
+
+template <class T>
+void launch_b2t_expand(const T* vout, long ldv, long n, int b, T* vx, T* taus, hipStream_t stream) {
+  const int nblk = (int) ((n + b - 1) / b);
+  if (nblk <= 0)
+    return;
+  hipLaunchKernelGGL((b2t_expand_kernel<T>), dim3((unsigned) nblk, (unsigned) nblk), dim3(kThreads), 0, stream, vout, ldv, n,
+                     b, nblk, vx, taus);
+}
+
+#define INST(T)                                                                                                      \
+  template void launch_band_extract<T>(const T*, long, int, int, int, int, int, long, int, T*, hipStream_t);        \
+  template void launch_tridiag_extract<T>(const T*, long, int, real_t<T>*, real_t<T>*, hipStream_t);                \
+  template void launch_band_to_tridiag<T>(T*, long, int, T*, long, unsigned*, int*, hipStream_t);                   \
+  template void launch_b2t_expand<T>(const T*, long, long, int, T*, T*, hipStream_t);                                \
+  template void launch_rows_to_tiles<T>(const T*, long, long, long, int, int, int, long, long, T*, hipStream_t);
+INST(float)
+INST(double)
+INST(cfloat)
+INST(cdouble)
+#undef INST
+
+}  // namespace dlaf_mi355x

@@ -16,11 +16,14 @@
 #include <string>
 #include <unordered_map>
 
+#include <dlaf_c/eigensolver/eigensolver.h>
+#include <dlaf_c/eigensolver/gen_eigensolver.h>
 #include <dlaf_c/factorization/cholesky.h>
 #include <dlaf_c/grid.h>
 #include <dlaf_c/init.h>
 #include <dlaf_mi355x/dlaf_mi355x.h>
 
+#include "eigensolver.hpp"
 #include "red2band.hpp"
 #include "runtime.hpp"
 #include "tile_matrix.hpp"
@@ -273,6 +276,107 @@ int bt_red2band_c(int ctx, int band, HT* c, const DLAF_descriptor& dc, const HT*
   return bt_reduction_to_band_host<DT>(&g, band, reinterpret_cast<DT*>(c), dc.ld, dc.n, dc.jsrc,
                                        reinterpret_cast<const DT*>(v), dv.ld, dv.m, dv.nb, dv.isrc, dv.jsrc,
                                        reinterpret_cast<const DT*>(taus));
+}
+
+
+// ---- the eigensolver stages and drivers ------------------------------------------------------
+template <class HT>
+struct RealOf {
+  using type = HT;
+};
+template <class R>
+struct RealOf<std::complex<R>> {
+  using type = R;
+};
+
+template <class HT>
+int band_to_tridiag_c(int ctx, const HT* a, const DLAF_descriptor& da, int band, typename RealOf<HT>::type* d,
+                      typename RealOf<HT>::type* e, HT* v, int ldv) {
+  using DT = typename DevType<HT>::type;
+  check_cholesky_desc(da);  // square matrix, square block, no offsets: band_to_tridiag.h:76-80
+  Grid& g = grid_from_context(ctx);
+  if (da.isrc < 0 || da.isrc >= g.nprow || da.jsrc < 0 || da.jsrc >= g.npcol)
+    fatal("[dlaf_mi355x] source rank (%d,%d) outside the %d x %d grid\n", da.isrc, da.jsrc, g.nprow, g.npcol);
+  if (band < 2 || da.nb % band != 0)
+    fatal("[dlaf_mi355x] band_to_tridiagonal: band_size %d must be >= 2 and divide the block size %d "
+          "(band_to_tridiag.h:78-80)\n", band, da.nb);
+  if (ldv < std::max(1, da.m))
+    fatal("[dlaf_mi355x] band_to_tridiagonal: ldv = %d < n = %d\n", ldv, da.m);
+  return band_to_tridiag_host<DT>(&g, reinterpret_cast<const DT*>(a), da.ld, da.m, da.nb, da.isrc, da.jsrc, band, d, e,
+                                  reinterpret_cast<DT*>(v), ldv);
+}
+
+// Eigensolver entry (src/c_api/eigensolver/eigensolver.h:33-75): descriptors of A and of the eigenvector matrix
+template <class HT>
+int eigensolver_c(int ctx, char uplo, HT* a, const DLAF_descriptor& da, typename RealOf<HT>::type* w, HT* z,
+                  const DLAF_descriptor& dz) {
+  using DT = typename DevType<HT>::type;
+  check_cholesky_desc(da);
+  Grid& g = grid_from_context(ctx);
+  if (dz.i != 0 || dz.j != 0)
+    fatal("[dlaf_mi355x] eigensolver: sub-matrix offsets of Z must be 0 (eigensolver.h:44-45 upstream)\n");
+  if (dz.m != da.m || dz.n != da.n || dz.mb != da.mb || dz.nb != da.nb)
+    fatal("[dlaf_mi355x] eigensolver: Z (%d x %d, block %d x %d) must have A's size %d x %d and block %d x %d\n", dz.m, dz.n,
+          dz.mb, dz.nb, da.m, da.n, da.mb, da.nb);
+  for (const DLAF_descriptor* d : {&da, &dz})
+    if (d->isrc < 0 || d->isrc >= g.nprow || d->jsrc < 0 || d->jsrc >= g.npcol)
+      fatal("[dlaf_mi355x] source rank (%d,%d) outside the %d x %d grid\n", d->isrc, d->jsrc, g.nprow, g.npcol);
+  return hermitian_eigensolver_host<DT>(&g, uplo, reinterpret_cast<DT*>(a), da.ld, da.m, da.nb, da.isrc, da.jsrc, w,
+                                        reinterpret_cast<DT*>(z), dz.ld, dz.isrc, dz.jsrc);
+}
+
+template <class HT>
+int gen_eigensolver_c(int ctx, char uplo, HT* a, const DLAF_descriptor& da, HT* b, const DLAF_descriptor& db,
+                      typename RealOf<HT>::type* w, HT* z, const DLAF_descriptor& dz, bool factorized) {
+  using DT = typename DevType<HT>::type;
+  check_cholesky_desc(da);
+  check_cholesky_desc(db);
+  Grid& g = grid_from_context(ctx);
+  if (dz.i != 0 || dz.j != 0)
+    fatal("[dlaf_mi355x] gen_eigensolver: sub-matrix offsets of Z must be 0\n");
+  for (const DLAF_descriptor* d : {&db, &dz})
+    if (d->m != da.m || d->n != da.n || d->mb != da.mb || d->nb != da.nb)
+      fatal("[dlaf_mi355x] gen_eigensolver: B and Z must have A's size %d x %d and block %d x %d\n", da.m, da.n, da.mb,
+            da.nb);
+  for (const DLAF_descriptor* d : {&da, &db, &dz})
+    if (d->isrc < 0 || d->isrc >= g.nprow || d->jsrc < 0 || d->jsrc >= g.npcol)
+      fatal("[dlaf_mi355x] source rank (%d,%d) outside the %d x %d grid\n", d->isrc, d->jsrc, g.nprow, g.npcol);
+  return hermitian_gen_eigensolver_host<DT>(&g, uplo, reinterpret_cast<DT*>(a), da.ld, reinterpret_cast<DT*>(b), db.ld,
+                                            da.m, da.nb, da.isrc, da.jsrc, db.isrc, db.jsrc, w, reinterpret_cast<DT*>(z),
+                                            dz.ld, dz.isrc, dz.jsrc, factorized);
+}
+
+// p?syevd / p?heevd and p?sygvd / p?hegvd argument lists (src/c_api/eigensolver/eigensolver.h:79-124)
+template <class HT>
+void pxheevd(char uplo, int n, HT* a, int ia, int ja, const int desca[9], typename RealOf<HT>::type* w, HT* z, int iz,
+             int jz, const int descz[9], int* info) {
+  if (desca[0] != 1 || descz[0] != 1)
+    fatal("[dlaf_mi355x] desc[0] (dtype) must be 1\n");
+  if (ia != 1 || ja != 1 || iz != 1 || jz != 1)
+    fatal("[dlaf_mi355x] ia, ja, iz, jz must be 1\n");
+  if (desca[1] != descz[1])
+    fatal("[dlaf_mi355x] A and Z live on different contexts (%d, %d)\n", desca[1], descz[1]);
+  const DLAF_descriptor da = make_dlaf_descriptor(n, n, ia, ja, desca);
+  const DLAF_descriptor dz = make_dlaf_descriptor(n, n, iz, jz, descz);
+  const int r = eigensolver_c<HT>(desca[1], uplo, a, da, w, z, dz);
+  if (info)
+    *info = r;
+}
+template <class HT>
+void pxhegvd(char uplo, int n, HT* a, int ia, int ja, const int desca[9], HT* b, int ib, int jb, const int descb[9],
+             typename RealOf<HT>::type* w, HT* z, int iz, int jz, const int descz[9], int* info, bool factorized) {
+  if (desca[0] != 1 || descb[0] != 1 || descz[0] != 1)
+    fatal("[dlaf_mi355x] desc[0] (dtype) must be 1\n");
+  if (ia != 1 || ja != 1 || ib != 1 || jb != 1 || iz != 1 || jz != 1)
+    fatal("[dlaf_mi355x] ia, ja, ib, jb, iz, jz must be 1\n");
+  if (desca[1] != descb[1] || desca[1] != descz[1])
+    fatal("[dlaf_mi355x] A, B and Z live on different contexts\n");
+  const DLAF_descriptor da = make_dlaf_descriptor(n, n, ia, ja, desca);
+  const DLAF_descriptor db = make_dlaf_descriptor(n, n, ib, jb, descb);
+  const DLAF_descriptor dz = make_dlaf_descriptor(n, n, iz, jz, descz);
+  const int r = gen_eigensolver_c<HT>(desca[1], uplo, a, da, b, db, w, z, dz, factorized);
+  if (info)
+    *info = r;
 }
 
 struct MatrixHandle {
@@ -579,6 +683,74 @@ DLAF_MI355X_R2B_ENTRY(d, double, double)
 DLAF_MI355X_R2B_ENTRY(c, std::complex<float>, dlaf_complex_c)
 DLAF_MI355X_R2B_ENTRY(z, std::complex<double>, dlaf_complex_z)
 #undef DLAF_MI355X_R2B_ENTRY
+
+
+#define DLAF_MI355X_EIG_ENTRY(S, KIND, HT, CT, RT, PEV, PGV)                                                          \
+  int dlaf_mi355x_band_to_tridiagonal_##S(int ctx, const CT* a, DLAF_descriptor desca, int band, RT* d, RT* e, CT* v, \
+                                          int ldv) noexcept {                                                       \
+    return band_to_tridiag_c<HT>(ctx, reinterpret_cast<const HT*>(a), desca, band, d, e, reinterpret_cast<HT*>(v), ldv); \
+  }                                                                                                                  \
+  int dlaf_mi355x_bt_band_to_tridiagonal_##S(int band, int n, int ncols, const CT* v, int ldv, CT* e, int lde) noexcept { \
+    using DT = typename DevType<HT>::type;                                                                           \
+    runtime_init();                                                                                                  \
+    if (band < 2 || ldv < std::max(1, n) || lde < std::max(1, n))                                                    \
+      fatal("[dlaf_mi355x] bt_band_to_tridiagonal: bad band_size / leading dimensions\n");                           \
+    return bt_band_to_tridiag_host<DT>(n, band, reinterpret_cast<const DT*>(v), ldv, reinterpret_cast<DT*>(e), lde,   \
+                                       ncols);                                                                       \
+  }                                                                                                                  \
+  int dlaf_##KIND##_eigensolver_##S(const int ctx, const char uplo, CT* a, const DLAF_descriptor desca, RT* w, CT* z, \
+                                    const DLAF_descriptor descz) noexcept {                                          \
+    return eigensolver_c<HT>(ctx, uplo, reinterpret_cast<HT*>(a), desca, w, reinterpret_cast<HT*>(z), descz);        \
+  }                                                                                                                  \
+  int dlaf_##KIND##_generalized_eigensolver_##S(const int ctx, const char uplo, CT* a, const DLAF_descriptor desca,   \
+                                                CT* b, const DLAF_descriptor descb, RT* w, CT* z,                    \
+                                                const DLAF_descriptor descz) noexcept {                              \
+    return gen_eigensolver_c<HT>(ctx, uplo, reinterpret_cast<HT*>(a), desca, reinterpret_cast<HT*>(b), descb, w,      \
+                                 reinterpret_cast<HT*>(z), descz, false);                                            \
+  }                                                                                                                  \
+  int dlaf_##KIND##_generalized_eigensolver_factorized_##S(const int ctx, const char uplo, CT* a,                     \
+                                                           const DLAF_descriptor desca, CT* b,                       \
+                                                           const DLAF_descriptor descb, RT* w, CT* z,                \
+                                                           const DLAF_descriptor descz) noexcept {                   \
+    return gen_eigensolver_c<HT>(ctx, uplo, reinterpret_cast<HT*>(a), desca, reinterpret_cast<HT*>(b), descb, w,      \
+                                 reinterpret_cast<HT*>(z), descz, true);                                             \
+  }                                                                                                                  \
+  void dlaf_##PEV(const char uplo, const int n, CT* a, const int ia, const int ja, const int desca[9], RT* w, CT* z,  \
+                  const int iz, const int jz, const int descz[9], int* info) noexcept {                              \
+    pxheevd<HT>(uplo, n, reinterpret_cast<HT*>(a), ia, ja, desca, w, reinterpret_cast<HT*>(z), iz, jz, descz, info);  \
+  }                                                                                                                  \
+  void dlaf_##PGV(const char uplo, const int n, CT* a, const int ia, const int ja, const int desca[9], CT* b,         \
+                  const int ib, const int jb, const int descb[9], RT* w, CT* z, const int iz, const int jz,          \
+                  const int descz[9], int* info) noexcept {                                                          \
+    pxhegvd<HT>(uplo, n, reinterpret_cast<HT*>(a), ia, ja, desca, reinterpret_cast<HT*>(b), ib, jb, descb, w,         \
+                reinterpret_cast<HT*>(z), iz, jz, descz, info, false);                                               \
+  }                                                                                                                  \
+  void dlaf_##PGV##_factorized(const char uplo, const int n, CT* a, const int ia, const int ja, const int desca[9],   \
+                               CT* b, const int ib, const int jb, const int descb[9], RT* w, CT* z, const int iz,    \
+                               const int jz, const int descz[9], int* info) noexcept {                               \
+    pxhegvd<HT>(uplo, n, reinterpret_cast<HT*>(a), ia, ja, desca, reinterpret_cast<HT*>(b), ib, jb, descb, w,         \
+                reinterpret_cast<HT*>(z), iz, jz, descz, info, true);                                                \
+  }
+DLAF_MI355X_EIG_ENTRY(s, symmetric, float, float, float, pssyevd, pssygvd)
+DLAF_MI355X_EIG_ENTRY(d, symmetric, double, double, double, pdsyevd, pdsygvd)
+DLAF_MI355X_EIG_ENTRY(c, hermitian, std::complex<float>, dlaf_complex_c, float, pcheevd, pchegvd)
+DLAF_MI355X_EIG_ENTRY(z, hermitian, std::complex<double>, dlaf_complex_z, double, pzheevd, pzhegvd)
+#undef DLAF_MI355X_EIG_ENTRY
+
+int dlaf_mi355x_tridiagonal_eigensolver_s(int n, int nb, const float* d, const float* e, float* w, float* z,
+                                          int ldz) noexcept {
+  runtime_init();
+  return tridiag_solver_host<float>(n, nb, d, e, w, z, ldz);
+}
+int dlaf_mi355x_tridiagonal_eigensolver_d(int n, int nb, const double* d, const double* e, double* w, double* z,
+                                          int ldz) noexcept {
+  runtime_init();
+  return tridiag_solver_host<double>(n, nb, d, e, w, z, ldz);
+}
+int dlaf_mi355x_eigensolver_profile(double ms[5]) noexcept {
+  eigensolver_last_profile(ms);
+  return 0;
+}
 
 int dlaf_mi355x_get_band_size(int nb) noexcept {
   return get_band_size(nb);

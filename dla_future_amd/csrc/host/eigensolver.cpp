@@ -1,0 +1,446 @@
+// eigensolver.cpp -- band -> tridiagonal, the back-transformation band <- tridiagonal, and the drivers of the
+// Hermitian (generalized) eigensolver (BASELINE configuration 5).
+//
+// Reference: Eigensolver::call (include/dlaf/eigensolver/eigensolver/impl.h:38-55 local, :57-95 distributed):
+//   reduction_to_band -> band_to_tridiagonal<Backend::MC> -> tridiagonal_eigensolver -> bt_band_to_tridiagonal ->
+//   bt_reduction_to_band;  GenEigensolver::call (gen_eigensolver/impl.h:33-92): cholesky_factorization of B,
+//   generalized_to_standard, the eigensolver, triangular_solver (Left, uplo, ConjTrans) on the eigenvectors.
+//   band_to_tridiagonal: band_to_tridiag/mc.h:681-867 (local), :1016-1558 (distributed, a pipeline of sweeps over
+//   1-D blocks of the band with point-to-point messages); bt_band_to_tridiagonal: bt_band_to_tridiag/impl.h:609-736.
+//
+// MI355X design.  The band (2 b n elements: 42 MB at n = 20480) and the tridiagonal problem are small next to one
+// GPU's memory and bandwidth, so a process grid does not pipeline them over ranks: the band is summed over the grid
+// (one all-reduce), the bulge chase runs replicated, ONE launch per rank (kernels_tridiag.hip); what is distributed
+// is what costs n^3: the eigenvector matrix of the back-transformations.
+//   bt_band_to_tridiagonal: the b x b blocks of compact reflectors become well-formed 2b x b blocks V with their
+//   T factors (all blocks at once: one expand launch, three strided-batch launches), then the blocks are applied in
+//   WAVEFRONTS -- block (jb, step) touches rows [1 + (jb + step) b, +2b) and must follow (jb, step - 1) and the blocks
+//   of sweep group jb + 1 that overlap it, so all blocks with the same step - jb are independent: W2 = V^H E and
+//   E -= (V T) W2 run as two strided-batch GEMM launches per wavefront instead of two per block.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "../device/band_api.hpp"
+#include "../device/tridiag_api.hpp"
+#include "eigensolver.hpp"
+
+namespace dlaf_mi355x {
+
+namespace {
+template <class T>
+T* ealloc(size_t elems) {
+  T* p = nullptr;
+  DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(elems, 1) * sizeof(T)));
+  return p;
+}
+double g_stage_ms[5] = {0, 0, 0, 0, 0};
+
+struct StageTimer {
+  hipEvent_t a, b;
+  hipStream_t s;
+  explicit StageTimer(hipStream_t st) : s(st) {
+    DLAF_HIP_CHECK(hipEventCreate(&a));
+    DLAF_HIP_CHECK(hipEventCreate(&b));
+    DLAF_HIP_CHECK(hipEventRecord(a, s));
+  }
+  double stop() {
+    DLAF_HIP_CHECK(hipEventRecord(b, s));
+    DLAF_HIP_CHECK(hipEventSynchronize(b));
+    float ms = 0;
+    DLAF_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+    DLAF_HIP_CHECK(hipEventDestroy(a));
+    DLAF_HIP_CHECK(hipEventDestroy(b));
+    return ms;
+  }
+};
+}  // namespace
+
+void eigensolver_last_profile(double ms[5]) {
+  for (int i = 0; i < 5; ++i)
+    ms[i] = g_stage_ms[i];
+}
+void eigensolver_set_stage_ms(int stage, double ms) {
+  g_stage_ms[stage] = ms;
+}
+
+// ------------------------------------------------------------------------------------------------ band -> tridiagonal
+template <class T>
+int band_to_tridiag_device(DeviceMatrix<T>& A, int band, real_t<T>* d, real_t<T>* e, T* v, long ldv) {
+  if (A.transposed)
+    fatal("[dlaf_mi355x] band_to_tridiagonal: the matrix must be held as uplo = L (band_to_tridiag.h:82-92: Upper is "
+          "not implemented upstream either)\n");
+  if (band < 2 || A.nb % band != 0)
+    fatal("[dlaf_mi355x] band_to_tridiagonal: band_size %d must be >= 2 and divide the block size %d "
+          "(band_to_tridiag.h:78-80)\n", band, A.nb);
+  if (band > b2t_max_band())
+    fatal("[dlaf_mi355x] band_to_tridiagonal: band_size %d above the supported %d\n", band, b2t_max_band());
+  Grid* grid = A.grid;
+  Transport* tr = grid_transport(*grid);
+  const bool dist = grid->nranks > 1;
+  if (dist && !tr)
+    fatal("[dlaf_mi355x] grid with %d ranks has no transport\n", grid->nranks);
+  const long n = A.n;
+  hipStream_t s = A.s_high;
+  DLAF_HIP_CHECK(hipMemsetAsync(A.info, 0, sizeof(int), s));
+  if (n == 0)
+    return 0;
+  StageTimer timer(s);
+  T* bandm = ealloc<T>((size_t) (n + 2) * 2 * band);
+  unsigned* sync = ealloc<unsigned>(b2t_sync_words(n));
+  launch_band_extract(A.tiles, A.ltr, A.nb, A.rows.P, A.rows.shift(), A.cols.P, A.cols.shift(), n, band, bandm, s);
+  if (dist)
+    tr->allreduce_sum(bandm, (size_t) n * 2 * band, TypeInfo<T>::tag, 'A', s);
+  DLAF_HIP_CHECK(hipMemset2DAsync(v, (size_t) ldv * sizeof(T), 0, (size_t) n * sizeof(T), (size_t) n, s));
+  launch_band_to_tridiag(bandm, n, band, v, ldv, sync, A.info, s);
+  launch_tridiag_extract(bandm, n, band, d, e, s);
+  int h_info = 0;
+  DLAF_HIP_CHECK(hipMemcpyAsync(&h_info, A.info, sizeof(int), hipMemcpyDeviceToHost, s));
+  g_stage_ms[1] = timer.stop();
+  DLAF_HIP_CHECK(hipFree(bandm));
+  DLAF_HIP_CHECK(hipFree(sync));
+  if (h_info == kInfoSchedulingFailure)
+    fatal("[dlaf_mi355x] band_to_tridiagonal: a sweep gave up waiting for its predecessor (the workgroup that owns it "
+          "made no progress)\n");
+  return h_info;
+}
+
+template <class T>
+int band_to_tridiag_host(Grid* g, const T* a, long lda, long n, int nb, int isrc, int jsrc, int band, real_t<T>* d,
+                         real_t<T>* e, T* v, long ldv) {
+  using R = real_t<T>;
+  DeviceMatrix<T> A;
+  A.create(g, 'L', n, nb, isrc, jsrc);
+  A.upload(a, lda);
+  R* dd = ealloc<R>((size_t) n);
+  R* de = ealloc<R>((size_t) n);
+  T* dv = ealloc<T>((size_t) n * n);
+  const int r = band_to_tridiag_device(A, band, dd, de, dv, n);
+  if (n > 0) {
+    DLAF_HIP_CHECK(hipMemcpy(d, dd, (size_t) n * sizeof(R), hipMemcpyDeviceToHost));
+    DLAF_HIP_CHECK(hipMemcpy(e, de, (size_t) n * sizeof(R), hipMemcpyDeviceToHost));
+    DLAF_HIP_CHECK(hipMemcpy2D(v, (size_t) ldv * sizeof(T), dv, (size_t) n * sizeof(T), (size_t) n * sizeof(T), (size_t) n,
+                               hipMemcpyDeviceToHost));
+  }
+  DLAF_HIP_CHECK(hipFree(dd));
+  DLAF_HIP_CHECK(hipFree(de));
+  DLAF_HIP_CHECK(hipFree(dv));
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------ band <- tridiagonal
+template <class T>
+int bt_band_to_tridiag_device(long n, int band, const T* v, long ldv, T* e, long lde, long ncols, hipStream_t s) {
+  const int b = band;
+  const long nsweeps = TypeInfo<T>::is_complex ? n - 1 : n - 2;
+  if (nsweeps <= 0 || ncols <= 0)
+    return 0;
+  if (ncols > 0x7fffffffL || n > 0x7fffffffL)
+    fatal("[dlaf_mi355x] bt_band_to_tridiagonal: sizes beyond 32-bit tile counts\n");
+  const long nblk = (n + b - 1) / b;
+  const size_t vblk = (size_t) 2 * b * b;
+  const size_t nb2 = (size_t) nblk * nblk;
+  T* vx = ealloc<T>(nb2 * vblk);
+  T* wx = ealloc<T>(nb2 * vblk);
+  T* sm = ealloc<T>(nb2 * (size_t) b * b);
+  T* tm = ealloc<T>(nb2 * (size_t) b * b);
+  T* taus = ealloc<T>(nb2 * (size_t) b);
+  DLAF_HIP_CHECK(hipMemsetAsync(vx, 0, nb2 * vblk * sizeof(T), s));
+  DLAF_HIP_CHECK(hipMemsetAsync(taus, 0, nb2 * (size_t) b * sizeof(T), s));
+  launch_b2t_expand(v, ldv, n, b, vx, taus, s);
+  const T one = make_host_el<T>(1.0), zero = make_host_el<T>(0.0), mone = make_host_el<T>(-1.0);
+  {
+    GemmArgs<T> g;  // S = V^H V
+    g.M = b;
+    g.N = b;
+    g.K = 2 * b;
+    g.a = vx;
+    g.lda = 2 * b;
+    g.opa = 'C';
+    g.b = vx;
+    g.ldb = 2 * b;
+    g.opb = 'N';
+    g.c = sm;
+    g.ldc = b;
+    g.alpha = one;
+    g.beta = zero;
+    g.batch = (int) nb2;
+    g.sa = (long) vblk;
+    g.sb = (long) vblk;
+    g.sc = (long) b * b;
+    launch_gemm(g, s);
+  }
+  launch_tfactor(sm, (long) b, taus, b, tm, (long) b, s, (int) nb2, (long) b * b, (long) b, (long) b * b);
+  {
+    GemmArgs<T> g;  // W = V T
+    g.M = 2 * b;
+    g.N = b;
+    g.K = b;
+    g.a = vx;
+    g.lda = 2 * b;
+    g.opa = 'N';
+    g.b = tm;
+    g.ldb = b;
+    g.opb = 'N';
+    g.c = wx;
+    g.ldc = 2 * b;
+    g.alpha = one;
+    g.beta = zero;
+    g.batch = (int) nb2;
+    g.sa = (long) vblk;
+    g.sb = (long) b * b;
+    g.sc = (long) vblk;
+    launch_gemm(g, s);
+  }
+  // steps of sweep group jb (its first sweep has the most)
+  auto steps_of = [&](long jb) -> long {
+    const long sw = jb * b;
+    if (sw >= nsweeps)
+      return 0;
+    if (TypeInfo<T>::is_complex && sw == n - 2)
+      return 1;
+    return (n - sw - 2 + b - 1) / b;
+  };
+  const long jb_last = (nsweeps - 1) / b;
+  const long max_batch = nblk / 2 + 2;
+  T* w2 = ealloc<T>((size_t) max_batch * b * (size_t) ncols);
+  // wavefront t = step - jb, from the last sweep group's first step to the first group's last step
+  const long t_lo = -jb_last, t_hi = steps_of(0) - 1;
+  for (long t = t_lo; t <= t_hi; ++t) {
+    const long jb0 = std::max<long>(0, -t);
+    // blocks (jb, st = t + jb), jb = jb0 ...: valid while st < steps_of(jb)
+    long cnt = 0, full = 0;
+    for (long jb = jb0; jb <= jb_last; ++jb) {
+      const long st = t + jb;
+      if (st >= steps_of(jb))
+        break;
+      const long r0 = 1 + (jb + st) * b;
+      if (r0 >= n)
+        break;
+      ++cnt;
+      if (r0 + 2 * b <= n)
+        ++full;
+    }
+    if (cnt == 0)
+      continue;
+    if (cnt > max_batch)
+      fatal("[dlaf_mi355x] bt_band_to_tridiagonal: wavefront of %ld blocks exceeds the workspace (%ld)\n", cnt, max_batch);
+    // the blocks of a wavefront: block index (jb, ib = 2 jb + t) -> stride nblk + 2 blocks; rows 1 + (2 jb + t) b ->
+    // stride 2 b rows of E
+    auto run = [&](long first, long count, long rows) {
+      if (count <= 0)
+        return;
+      const long jb = jb0 + first;
+      const long ib = 2 * jb + t;
+      const long blk = jb * nblk + ib;
+      const long r0 = 1 + ib * b;
+      GemmArgs<T> g;  // W2 = V^H E
+      g.M = b;
+      g.N = (int) ncols;
+      g.K = (int) rows;
+      g.a = vx + (size_t) blk * vblk;
+      g.lda = 2 * b;
+      g.opa = 'C';
+      g.b = e + r0;
+      g.ldb = lde;
+      g.opb = 'N';
+      g.c = w2;
+      g.ldc = b;
+      g.alpha = one;
+      g.beta = zero;
+      g.batch = (int) count;
+      g.sa = (long) ((nblk + 2) * (long) vblk);
+      g.sb = 2L * b;
+      g.sc = (long) b * ncols;
+      launch_gemm(g, s);
+      GemmArgs<T> u;  // E -= W W2
+      u.M = (int) rows;
+      u.N = (int) ncols;
+      u.K = b;
+      u.a = wx + (size_t) blk * vblk;
+      u.lda = 2 * b;
+      u.opa = 'N';
+      u.b = w2;
+      u.ldb = b;
+      u.opb = 'N';
+      u.c = e + r0;
+      u.ldc = lde;
+      u.alpha = mone;
+      u.beta = one;
+      u.batch = (int) count;
+      u.sa = (long) ((nblk + 2) * (long) vblk);
+      u.sb = (long) b * ncols;
+      u.sc = 2L * b;
+      launch_gemm(u, s);
+    };
+    run(0, full, 2L * b);
+    for (long q = full; q < cnt; ++q) {
+      const long ib = 2 * (jb0 + q) + t;
+      run(q, 1, n - (1 + ib * b));
+    }
+  }
+  DLAF_HIP_CHECK(hipStreamSynchronize(s));
+  for (T* q : {vx, wx, sm, tm, taus, w2})
+    DLAF_HIP_CHECK(hipFree(q));
+  return 0;
+}
+
+template <class T>
+int bt_band_to_tridiag_host(long n, int band, const T* v, long ldv, T* e, long lde, long ncols) {
+  if (n <= 0 || ncols <= 0)
+    return 0;
+  hipStream_t s;
+  DLAF_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  T* dv = ealloc<T>((size_t) n * n);
+  T* de = ealloc<T>((size_t) n * ncols);
+  DLAF_HIP_CHECK(hipMemcpy2DAsync(dv, (size_t) n * sizeof(T), v, (size_t) ldv * sizeof(T), (size_t) n * sizeof(T), (size_t) n,
+                                  hipMemcpyHostToDevice, s));
+  DLAF_HIP_CHECK(hipMemcpy2DAsync(de, (size_t) n * sizeof(T), e, (size_t) lde * sizeof(T), (size_t) n * sizeof(T),
+                                  (size_t) ncols, hipMemcpyHostToDevice, s));
+  StageTimer timer(s);
+  const int r = bt_band_to_tridiag_device(n, band, dv, n, de, n, ncols, s);
+  g_stage_ms[3] = timer.stop();
+  DLAF_HIP_CHECK(hipMemcpy2DAsync(e, (size_t) lde * sizeof(T), de, (size_t) n * sizeof(T), (size_t) n * sizeof(T),
+                                  (size_t) ncols, hipMemcpyDeviceToHost, s));
+  DLAF_HIP_CHECK(hipStreamSynchronize(s));
+  DLAF_HIP_CHECK(hipFree(dv));
+  DLAF_HIP_CHECK(hipFree(de));
+  DLAF_HIP_CHECK(hipStreamDestroy(s));
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------ drivers
+// Eigensolver::call on resident operands: A (uplo L; destroyed: band + reflectors), eigenvalues to the host array w
+// (all n on every rank), eigenvectors into the resident general matrix Z (n x n, A's block size and row source).
+template <class T>
+int hermitian_eigensolver_device(DeviceMatrix<T>& A, real_t<T>* w_host, GeneralMatrix<T>& Z) {
+  using R = real_t<T>;
+  const long n = A.n;
+  const int nb = A.nb;
+  if (n == 0)
+    return 0;
+  Grid* g = A.grid;
+  TileMatrix<T>& C = Z.m;
+  if (C.grid != g || C.nb != nb || C.rows.n != n || C.cols.n != n || C.rows.src != A.rows.src || C.transposed)
+    fatal("[dlaf_mi355x] eigensolver: the eigenvector matrix must be n x n with A's block size and row source rank\n");
+  const int band = get_band_size(nb);  // eigensolver/impl.h:41
+  hipStream_t s = A.s_high;
+  std::vector<T> taus((size_t) std::max<long>(0, n - band - 1) + 1);
+  int info = reduction_to_band_device(A, band, taus.data());
+  {
+    double ms = 0, fl = 0;
+    red2band_last_profile(&ms, &fl);
+    g_stage_ms[0] = ms;
+  }
+  if (info != 0)
+    return info;
+  R* d = ealloc<R>((size_t) n);
+  R* e = ealloc<R>((size_t) n);
+  T* v = ealloc<T>((size_t) n * n);
+  info = band_to_tridiag_device(A, band, d, e, v, n);
+  R* wd = ealloc<R>((size_t) n);
+  R* zr = ealloc<R>((size_t) n * n);
+  {
+    StageTimer t(s);
+    tridiag_solver_device<R>(n, nb, d, e, wd, zr, n, s);
+    g_stage_ms[2] = t.stop();
+  }
+  DLAF_HIP_CHECK(hipMemcpyAsync(w_host, wd, (size_t) n * sizeof(R), hipMemcpyDeviceToHost, s));
+  // the columns of this process column, all rows (the back-transformation mixes rows, never columns)
+  const long ncl = C.cols.local_size();
+  T* el = ealloc<T>((size_t) n * std::max<long>(ncl, 1));
+  launch_cols_gather_cast<R, T>(zr, n, n, nb, C.cols.P, C.cols.shift(), ncl, el, n, s);
+  {
+    StageTimer t(s);
+    bt_band_to_tridiag_device(n, band, v, n, el, n, ncl, s);
+    g_stage_ms[3] = t.stop();
+  }
+  launch_rows_to_tiles(el, n, n, ncl, nb, C.rows.P, C.rows.shift(), C.ltr, C.ltc, C.tiles, s);
+  DLAF_HIP_CHECK(hipStreamSynchronize(s));
+  for (R* q : {d, e, wd, zr})
+    DLAF_HIP_CHECK(hipFree(q));
+  DLAF_HIP_CHECK(hipFree(v));
+  DLAF_HIP_CHECK(hipFree(el));
+  info = bt_reduction_to_band_device(band, C, A, taus.data());
+  {
+    double ms = 0, fl = 0;
+    red2band_last_profile(&ms, &fl);
+    g_stage_ms[4] = ms;
+  }
+  return info;
+}
+
+template <class T>
+int hermitian_eigensolver_host(Grid* g, char uplo, T* a, long lda, long n, int nb, int isrc, int jsrc, real_t<T>* w, T* z,
+                               long ldz, int z_isrc, int z_jsrc) {
+  if (uplo != 'L' && uplo != 'l')
+    fatal("[dlaf_mi355x] eigensolver: uplo = %c is not implemented (neither upstream: eigensolver/impl.h:43-45)\n", uplo);
+  if (z_isrc != isrc)
+    fatal("[dlaf_mi355x] eigensolver: the eigenvector matrix must share A's row source rank (%d != %d)\n", z_isrc, isrc);
+  DeviceMatrix<T> A;
+  A.create(g, 'L', n, nb, isrc, jsrc);
+  A.upload(a, lda);
+  std::unique_ptr<MatrixBase> zh(general_matrix_create(g, TypeInfo<T>::tag, n, n, nb, z_isrc, z_jsrc));
+  GeneralMatrix<T>& Z = static_cast<GeneralMatrix<T>&>(*zh);
+  const int r = hermitian_eigensolver_device(A, w, Z);
+  A.download(a, lda, true);  // (upstream leaves the band + reflectors in A as well)
+  general_matrix_transfer(zh.get(), z, ldz, false);
+  return r;
+}
+
+template <class T>
+int hermitian_gen_eigensolver_host(Grid* g, char uplo, T* a, long lda, T* b, long ldb, long n, int nb, int a_isrc,
+                                   int a_jsrc, int b_isrc, int b_jsrc, real_t<T>* w, T* z, long ldz, int z_isrc,
+                                   int z_jsrc, bool b_factorized) {
+  if (uplo != 'L' && uplo != 'l')
+    fatal("[dlaf_mi355x] gen_eigensolver: uplo = %c is not implemented (neither upstream: eigensolver/impl.h:43-45)\n", uplo);
+  if (a_isrc != b_isrc || a_jsrc != b_jsrc || z_isrc != a_isrc)
+    fatal("[dlaf_mi355x] gen_eigensolver: A, B and the eigenvector matrix must share their source rank\n");
+  DeviceMatrix<T> A, B;
+  A.create(g, 'L', n, nb, a_isrc, a_jsrc);
+  B.create(g, 'L', n, nb, b_isrc, b_jsrc);
+  A.upload(a, lda);
+  B.upload(b, ldb);
+  // gen_eigensolver/impl.h:33-60: cholesky_factorization(uplo, B) unless the caller passes the factor,
+  // generalized_to_standard(uplo, A, B), the eigensolver, triangular_solver(Left, uplo, ConjTrans, NonUnit, 1, B, Z)
+  int info = 0;
+  if (!b_factorized) {
+    info = B.factorize();
+    if (info != 0)
+      return info;
+  }
+  info = gen_to_std_device(A, B);
+  if (info != 0)
+    return info;
+  std::unique_ptr<MatrixBase> zh(general_matrix_create(g, TypeInfo<T>::tag, n, n, nb, z_isrc, z_jsrc));
+  GeneralMatrix<T>& Z = static_cast<GeneralMatrix<T>&>(*zh);
+  info = hermitian_eigensolver_device(A, w, Z);
+  if (info != 0)
+    return info;
+  const T one = make_host_el<T>(1.0);
+  B.type = TypeInfo<T>::tag;
+  info = triangular_solver_device('L', 'L', 'C', 'N', &one, &B, zh.get());
+  A.download(a, lda, true);
+  if (!b_factorized)
+    B.download(b, ldb, true);
+  general_matrix_transfer(zh.get(), z, ldz, false);
+  return info;
+}
+
+#define INST(T)                                                                                                          \
+  template int hermitian_eigensolver_host<T>(Grid*, char, T*, long, long, int, int, int, real_t<T>*, T*, long, int, int); \
+  template int hermitian_gen_eigensolver_host<T>(Grid*, char, T*, long, T*, long, long, int, int, int, int, int,         \
+                                                 real_t<T>*, T*, long, int, int, bool);                                  \
+  template int band_to_tridiag_device<T>(DeviceMatrix<T>&, int, real_t<T>*, real_t<T>*, T*, long);                       \
+  template int band_to_tridiag_host<T>(Grid*, const T*, long, long, int, int, int, int, real_t<T>*, real_t<T>*, T*, long); \
+  template int bt_band_to_tridiag_device<T>(long, int, const T*, long, T*, long, long, hipStream_t);                     \
+  template int bt_band_to_tridiag_host<T>(long, int, const T*, long, T*, long, long);
+INST(float)
+INST(double)
+INST(cfloat)
+INST(cdouble)
+#undef INST
+
+}  // namespace dlaf_mi355x

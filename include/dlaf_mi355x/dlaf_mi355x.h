@@ -239,6 +239,43 @@ DLAF_EXTERN_C int dlaf_mi355x_get_band_size(int nb) DLAF_NOEXCEPT;
  * reduction_to_band / bt_reduction_to_band on this process */
 DLAF_EXTERN_C int dlaf_mi355x_red2band_profile(double* ms, double* flops) DLAF_NOEXCEPT;
 
+/* ---- the eigensolver stages behind reduction_to_band -------------------------------------- */
+/* dlaf::eigensolver::internal::band_to_tridiagonal<Backend::MC>(grid, uplo = Lower, band_size, mat_a)
+ * (include/dlaf/eigensolver/band_to_tridiag.h:74-97, :155-176; the reference has no C entry for the stage): a holds a
+ * Hermitian band matrix in the lower band of its local part (what reduction_to_band leaves; everything below the band
+ * is ignored).  d: n diagonal entries, e: n - 1 off-diagonal entries (real), v: n x n (ld ldv) compact Householder
+ * reflectors with tau in the place of the leading 1, laid out as band_to_tridiag.h:40-72 says.  The outputs are complete
+ * on every process. */
+DLAF_EXTERN_C int dlaf_mi355x_band_to_tridiagonal_s(int context, const float* a, struct DLAF_descriptor desca, int band_size,
+                                                  float* d, float* e, float* v, int ldv) DLAF_NOEXCEPT;
+DLAF_EXTERN_C int dlaf_mi355x_band_to_tridiagonal_d(int context, const double* a, struct DLAF_descriptor desca, int band_size,
+                                                  double* d, double* e, double* v, int ldv) DLAF_NOEXCEPT;
+DLAF_EXTERN_C int dlaf_mi355x_band_to_tridiagonal_c(int context, const dlaf_complex_c* a, struct DLAF_descriptor desca, int band_size,
+                                                  float* d, float* e, dlaf_complex_c* v, int ldv) DLAF_NOEXCEPT;
+DLAF_EXTERN_C int dlaf_mi355x_band_to_tridiagonal_z(int context, const dlaf_complex_z* a, struct DLAF_descriptor desca, int band_size,
+                                                  double* d, double* e, dlaf_complex_z* v, int ldv) DLAF_NOEXCEPT;
+/* dlaf::eigensolver::internal::bt_band_to_tridiagonal(band_size, mat_e, mat_hh)
+ * (include/dlaf/eigensolver/bt_band_to_tridiag.h:28-61), local form: e (n x ncols, column-major, ld lde) <- Q e with the
+ * reflectors v as band_to_tridiagonal returned them */
+DLAF_EXTERN_C int dlaf_mi355x_bt_band_to_tridiagonal_s(int band_size, int n, int ncols, const float* v, int ldv, float* e,
+                                                     int lde) DLAF_NOEXCEPT;
+DLAF_EXTERN_C int dlaf_mi355x_bt_band_to_tridiagonal_d(int band_size, int n, int ncols, const double* v, int ldv, double* e,
+                                                     int lde) DLAF_NOEXCEPT;
+DLAF_EXTERN_C int dlaf_mi355x_bt_band_to_tridiagonal_c(int band_size, int n, int ncols, const dlaf_complex_c* v, int ldv, dlaf_complex_c* e,
+                                                     int lde) DLAF_NOEXCEPT;
+DLAF_EXTERN_C int dlaf_mi355x_bt_band_to_tridiagonal_z(int band_size, int n, int ncols, const dlaf_complex_z* v, int ldv, dlaf_complex_z* e,
+                                                     int lde) DLAF_NOEXCEPT;
+/* dlaf::eigensolver::internal::tridiagonal_eigensolver (include/dlaf/eigensolver/tridiag_solver.h:30-60), local form:
+ * d (n), e (n - 1) -> eigenvalues w (ascending) and eigenvectors z (n x n, column-major, ld ldz) by divide & conquer on
+ * the GPU.  nb: the reference's block size (unused by the device algorithm, kept for the call shape). */
+DLAF_EXTERN_C int dlaf_mi355x_tridiagonal_eigensolver_s(int n, int nb, const float* d, const float* e, float* w, float* z,
+                                                        int ldz) DLAF_NOEXCEPT;
+DLAF_EXTERN_C int dlaf_mi355x_tridiagonal_eigensolver_d(int n, int nb, const double* d, const double* e, double* w,
+                                                        double* z, int ldz) DLAF_NOEXCEPT;
+/* device time (ms) per stage of the last eigensolver call on this process: reduction_to_band, band_to_tridiagonal,
+ * tridiagonal_eigensolver, bt_band_to_tridiagonal, bt_reduction_to_band */
+DLAF_EXTERN_C int dlaf_mi355x_eigensolver_profile(double ms[5]) DLAF_NOEXCEPT;
+
 /* Device-resident operands: a general m x n matrix in HBM (tile layout; square blocks) as the right-hand side,
  * a dlaf_mi355x_matrix_t (the uplo triangle of a resident matrix, e.g. the factor dlaf_mi355x_cholesky_* left there)
  * as the triangular matrix.  b is overwritten by the solution; nothing crosses PCIe.  potrs_device = the two solves of
