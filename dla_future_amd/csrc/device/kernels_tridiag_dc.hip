@@ -234,8 +234,21 @@ __global__ __launch_bounds__(kDcThreads) void dc_prepare_kernel(DcMergeArgs<R> p
   __syncthreads();
   // ---- deflation scan (applyDeflationToArrays, merge.h:696-760), one thread ---------------------------------------
   DcRot<R>* rots = p.rots + off;
+  int* dfl = p.dfl + off;
   if (tid == 0) {
     int nrot = 0;
+    int ndfl = 0;
+    // deflated entries in ascending order of their (final) values: a rotation moves an eigenvalue inside its cluster,
+    // so the order of deflation is ascending only up to the deflation tolerance -- insertion keeps the list sorted
+    // (LAPACK xLAED2 does the same with INDXP), which the merge of the next level relies on
+    auto push_deflated = [&](int idx, R val) {
+      int q = ndfl++;
+      while (q > 0 && dsrt[dfl[q - 1]] > val) {
+        dfl[q] = dfl[q - 1];
+        --q;
+      }
+      dfl[q] = idx;
+    };
     int i1 = 0;
     R d1 = dsrt[0], z1 = zsrt[0];
     int c1 = ctype[0];
@@ -245,6 +258,7 @@ __global__ __launch_bounds__(kDcThreads) void dc_prepare_kernel(DcMergeArgs<R> p
         dsrt[i1] = d1;
         zsrt[i1] = z1;
         ctype[i1] = 3;
+        push_deflated(i1, d1);
         i1 = i2;
         d1 = dsrt[i2];
         z1 = zsrt[i2];
@@ -255,6 +269,7 @@ __global__ __launch_bounds__(kDcThreads) void dc_prepare_kernel(DcMergeArgs<R> p
       const int c2 = ctype[i2];
       if (fabs(rho * z2) <= tol) {
         ctype[i2] = 3;
+        push_deflated(i2, d2);
         continue;
       }
       const R r = hypot(z1, z2);
@@ -282,12 +297,15 @@ __global__ __launch_bounds__(kDcThreads) void dc_prepare_kernel(DcMergeArgs<R> p
       if ((c1 == 0 && c2 == 2) || (c1 == 2 && c2 == 0))
         c1 = 1;
       ctype[i2] = 3;
+      push_deflated(i2, nd2);
     }
     if (fabs(rho * z1) <= tol)
       c1 = 3;
     dsrt[i1] = d1;
     zsrt[i1] = z1;
     ctype[i1] = c1;
+    if (c1 == 3)
+      push_deflated(i1, d1);
     // counts per type
     int cu = 0, cd = 0, cl = 0;
     for (int i = 0; i < n; ++i) {
@@ -313,15 +331,15 @@ __global__ __launch_bounds__(kDcThreads) void dc_prepare_kernel(DcMergeArgs<R> p
   //      takes the non-deflated poles in ascending order ------------------------------------------------------------
   // (serial prefix by one wave's lanes over chunks: n <= a few 10^4)
   if (wave == 0) {
-    int run[4] = {0, 0, 0, 0};
-    const int base[4] = {0, s_cnt[0], s_cnt[0] + s_cnt[1], s_cnt[0] + s_cnt[1] + s_cnt[2]};
+    int run[3] = {0, 0, 0};
+    const int base[3] = {0, s_cnt[0], s_cnt[0] + s_cnt[1]};
     int sec = 0;
     for (int i0 = 0; i0 < n; i0 += 64) {
       const int i = i0 + lane;
       const int t = i < n ? ctype[i] : -1;
-      int within[4];
+      int within[3];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < 3; ++q) {
         const unsigned long long mask = __ballot(t == q);
         within[q] = __popcll(mask & ((1ull << lane) - 1ull));
         if (t == q)
@@ -352,9 +370,14 @@ __global__ __launch_bounds__(kDcThreads) void dc_prepare_kernel(DcMergeArgs<R> p
   }
   // deflated eigenvalues go to their destination slot (the new storage order is the destination order)
   __syncthreads();
-  for (int i = tid; i < n; i += kDcThreads)
-    if (ctype[i] == 3)
-      p.dnew[off + p.tpos[off + srt[i]]] = dsrt[i];
+  {
+    const int k = s_cnt[0] + s_cnt[1] + s_cnt[2];
+    for (int q = tid; q < n - k; q += kDcThreads) {
+      const int i = dfl[q];
+      p.tpos[off + srt[i]] = k + q;
+      p.dnew[off + k + q] = dsrt[i];
+    }
+  }
 }
 
 // ======================================================================================= merge: rotations + gather

@@ -61,6 +61,7 @@ struct DcMergeArgs {
   int* ctype;
   int* tpos;
   int* sec2t;
+  int* dfl;    // deflated entries (positions in the merged order), ascending by value
   DcRot<R>* rots;
 };
 

@@ -95,7 +95,7 @@ int tridiag_solver_device(long n, int /*nb*/, R* d, R* e, R* w, R* z, long ldz, 
   R* dlt = dcalloc<R>((size_t) ldq * n);
   R* u = dcalloc<R>((size_t) ldq * n);
   R* rv = dcalloc<R>((size_t) n * 8);  // dnew, z, z2, zhat, dsrt, zsrt, dsec, zsec
-  int* iv = dcalloc<int>((size_t) n * 5);  // ord, srt, ctype, tpos, sec2t
+  int* iv = dcalloc<int>((size_t) n * 6);  // ord, srt, ctype, tpos, sec2t, dfl
   DcRot<R>* rots = dcalloc<DcRot<R>>((size_t) n);
   long* d_leaf_off = dcalloc<long>((size_t) nleaves + 1);
   int* d_leaf_n = dcalloc<int>((size_t) nleaves);
@@ -168,6 +168,7 @@ int tridiag_solver_device(long n, int /*nb*/, R* d, R* e, R* w, R* z, long ldz, 
     a.ctype = iv + 2 * n;
     a.tpos = iv + 3 * n;
     a.sec2t = iv + 4 * n;
+    a.dfl = iv + 5 * n;
     a.rots = rots;
     launch_dc_prepare(a, cnt, s);
     launch_dc_rotate_gather(a, cnt, nmax, s);
