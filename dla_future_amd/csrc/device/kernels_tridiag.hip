@@ -467,6 +467,322 @@ __global__ __launch_bounds__(kB2tThreads) void b2t_kernel(B2tArgs<T> p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same sweep-step algorithm with the block of a step held in REGISTERS (band sizes up to kB2tRegBand, element
+// types of up to 8 bytes).  Thread (wave w, lane l) owns the elements (row l + 64 q, column cc = w + NW k), q < 4,
+// k < CPW, of the block -- the same elements in every phase of the step, so a step loads each of them ONCE (all loads
+// of the step issued together: one memory latency instead of one per phase and column) and stores it once.  The ROWS
+// of a thread do not depend on the column: the entries of the vectors that multiply from the left (v, w, the new
+// reflector) that a thread ever needs are four registers each, loaded once per phase, and z = A v accumulates in four
+// registers per thread; per column there is one broadcast operand and one wave reduction.
+// Loads are sc1 buffer loads, which the compiler pipelines like plain loads (relaxed atomic loads, the other sc1 form,
+// it issues one at a time); an element outside the block is set to zero after its load and stored to an out-of-range
+// offset (dropped by the descriptor's bounds check), so a step is the same straight-line code for every element.
+constexpr int kB2tRegBand = 128;
+constexpr int kB2tExt = 2 * kB2tRegBand;  // rows of a block
+
+template <class T>
+__device__ __forceinline__ T buf_load_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off, unsigned soff) {
+  if constexpr (sizeof(T) == 4) {
+    return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(rsrc, byte_off, soff, 16));
+  }
+  else {
+    static_assert(sizeof(T) == 8, "register kernel: 4- and 8-byte elements");
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    const u2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, byte_off, soff, 16);
+    return __builtin_bit_cast(T, v);
+  }
+}
+template <class T>
+__device__ __forceinline__ void buf_store_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off, unsigned soff, const T& v) {
+  if constexpr (sizeof(T) == 4) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, byte_off, soff, 16);
+  }
+  else {
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), rsrc, byte_off, soff, 16);
+  }
+}
+
+template <class T, int NT>
+__global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
+  using R = real_t<T>;
+  constexpr int NW = NT / 64;
+  constexpr int CPW = kB2tRegBand / NW;  // columns of a block per wave
+  constexpr int QN = kB2tExt / 64;       // rows of a block per lane
+  constexpr unsigned kOob = 0xFFFFFFF0u;
+  extern __shared__ __attribute__((aligned(16))) unsigned char b2t_raw[];
+  const int b = p.b, ldb = 2 * b;
+  T* Lv = reinterpret_cast<T*>(b2t_raw);  // [v ; 0]: the reflector over the rows of the block
+  T* Lw = Lv + kB2tExt;                   // [w ; tau B v]
+  T* Lwd = Lw + kB2tExt;                  // [w ; 0]
+  T* Lv2 = Lwd + kB2tExt;                 // [0 ; v2]: the new reflector at the rows of B
+  T* Lcs = Lv2 + kB2tExt;                 // per column: (strictly lower D)^H v
+  T* Lzw = Lcs + kB2tRegBand;             // NW x kB2tExt partial products A v
+  T* Lsc = Lzw + (size_t) NW * kB2tExt;   // [0] tau, [1] tau2, [2] alpha, [3] beta
+  unsigned* Lslot = reinterpret_cast<unsigned*>(Lsc + 4);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long n = p.n;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(p.band, 0, (int) ((size_t) (n + 2) * ldb * sizeof(T)), 0x00020000);
+
+  for (;;) {
+    if (tid == 0)
+      *Lslot = __hip_atomic_fetch_add(p.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const long s = (long) *Lslot;
+    __syncthreads();
+    if (s >= p.nsweeps)
+      break;
+    auto wait_prev = [&](unsigned need) -> bool {
+      if (s == 0) {
+        __syncthreads();
+        return true;
+      }
+      if (tid == 0) {
+        unsigned v;
+        long spins = 0;
+        while ((v = __hip_atomic_load(p.progress + (s - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > p.spin_limit ||
+              ((spins & 255) == 0 && __hip_atomic_load(p.failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+            v = 0xFFFFFFFFu;
+            break;
+          }
+        }
+        *Lslot = v;
+      }
+      __syncthreads();
+      const unsigned r = *Lslot;
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      return r != 0xFFFFFFFFu;
+    };
+    auto publish = [&](unsigned value) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0)
+        __hip_atomic_store(p.progress + s, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    bool ok = wait_prev(1u);
+    const bool cx_last = TypeInfo<T>::is_complex && s == n - 2;
+    const int nsteps = cx_last ? 1 : (int) ((n - s - 2 + b - 1) / b);
+    if (ok) {
+      const int nn = (int) (n - s - 1 < b ? n - s - 1 : b);
+      T* col = p.band + s * ldb + 1;
+      for (int i = tid; i < kB2tExt; i += NT)
+        Lv[i] = i < nn ? ld_sc(col + i) : zero_el<T>();
+      __syncthreads();
+      if (wave == 0) {
+        T tau, beta;
+        wave_larfg(Lv, nn, lane, tau, beta);
+        if (lane == 0)
+          Lsc[0] = tau;
+        for (int i = lane; i < nn; i += 64)
+          st_wt(col + i, i == 0 ? beta : zero_el<T>());
+      }
+      __syncthreads();
+    }
+    for (int step = 0; step < nsteps && ok; ++step) {
+      const long j = 1 + s + (long) step * b;
+      const int nh = (int) (n - j < b ? n - j : b);
+      const long mrem = n - b - j;
+      const int m = (int) (mrem < 0 ? 0 : (mrem < b ? mrem : b));
+      const int rows = nh + m;
+      const T tau = Lsc[0];
+      {
+        const long pos = (s / b + step) * (long) b;
+        T* dst = p.vout + pos + s * p.ldv;
+        for (int i = tid; i < nh; i += NT)
+          dst[i] = i == 0 ? tau : Lv[i];
+      }
+      ok = wait_prev((unsigned) step + 2u);
+      if (!ok)
+        break;
+      // (the lane index is made opaque per step: otherwise the per-element masks and offsets are hoisted out of the
+      //  step loop and kept alive across it)
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      // ---- the block: all loads of the step; element (r, cc) lives at band[(j + cc) ldb + r - cc] ------------------------
+      T A[CPW][QN];
+      const unsigned base_off = (unsigned) ((j * ldb + ln) * (long) sizeof(T));
+#pragma unroll
+      for (int k = 0; k < CPW; ++k) {
+        const int cc = wave + NW * k;
+#pragma unroll
+        for (int q = 0; q < QN; ++q)
+          A[k][q] = buf_load_sc1<T>(rsrc, base_off + (unsigned) (64 * q * (int) sizeof(T)),
+                                    (unsigned) (cc * (ldb - 1) * (int) sizeof(T)));
+      }
+      T vr[QN], zacc[QN];
+#pragma unroll
+      for (int q = 0; q < QN; ++q) {
+        vr[q] = Lv[ln + 64 * q];
+        zacc[q] = zero_el<T>();
+      }
+      // ---- P1: z = A v over the rows of both blocks, cs = strictly-lower(D)^H v -----------------------------------------
+#pragma unroll
+      for (int k = 0; k < CPW; ++k) {
+        const int cc = wave + NW * k;
+        const T vc = Lv[cc];  // (zero beyond the reflector)
+        T part = zero_el<T>();
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+          const int r = ln + 64 * q;
+          const bool valid = cc < nh && r >= cc && r < rows;
+          T a = valid ? A[k][q] : zero_el<T>();
+          if (64 * q < kB2tRegBand && r == cc)
+            a = make_el<T>(re_of(a), R(0));  // the diagonal element
+          A[k][q] = a;
+          zacc[q] = c_add(zacc[q], c_mul(a, vc));
+          if (64 * q < kB2tRegBand)
+            part = c_add(part, r == cc ? zero_el<T>() : c_cmul(a, vr[q]));
+          else
+            part = c_add(part, c_cmul(a, vr[q]));  // (rows of B: vr is zero there)
+        }
+        part = wave_sum_t(part);
+        if (lane == 0)
+          Lcs[cc] = part;
+      }
+#pragma unroll
+      for (int q = 0; q < QN; ++q)
+        Lzw[(size_t) wave * kB2tExt + ln + 64 * q] = zacc[q];
+      __syncthreads();
+      // ---- P2: wx = [tau (z + cs) - 1/2 tau (w^H v) v ; tau B v ; 0] ----------------------------------------------------
+      for (int r = tid; r < kB2tExt; r += NT) {
+        T sum = zero_el<T>();
+#pragma unroll
+        for (int q = 0; q < NW; ++q)
+          sum = c_add(sum, Lzw[(size_t) q * kB2tExt + r]);
+        T w = zero_el<T>();
+        if (r < nh)
+          w = c_mul(tau, c_add(sum, Lcs[r]));
+        else if (r < rows)
+          w = c_mul(tau, sum);
+        Lw[r] = w;
+        Lv2[r] = zero_el<T>();
+        Lwd[r] = zero_el<T>();
+      }
+      __syncthreads();
+      if (wave == 0) {
+        T dot = zero_el<T>();
+        for (int r = lane; r < nh; r += 64)
+          dot = c_add(dot, c_cmul(Lw[r], Lv[r]));
+        dot = wave_sum_t(dot);
+        if (lane == 0)
+          Lsc[2] = c_scale(c_mul(dot, tau), R(-0.5));
+      }
+      __syncthreads();
+      {
+        const T alpha = Lsc[2];
+        for (int r = tid; r < nh; r += NT) {
+          const T w = c_add(Lw[r], c_mul(alpha, Lv[r]));
+          Lw[r] = w;
+          Lwd[r] = w;
+        }
+      }
+      __syncthreads();
+      // ---- P3: A -= wx conj(v_c) + vx conj(w_c)  (two-sided update of D, right update of B) -----------------------------
+      {
+        T wr[QN];
+#pragma unroll
+        for (int q = 0; q < QN; ++q)
+          wr[q] = Lw[ln + 64 * q];
+#pragma unroll
+        for (int k = 0; k < CPW; ++k) {
+          const int cc = wave + NW * k;
+          const T vcc = c_conj(Lv[cc]);
+          const T wcc = c_conj(Lwd[cc]);
+#pragma unroll
+          for (int q = 0; q < QN; ++q) {
+            const int r = ln + 64 * q;
+            const bool valid = r >= cc;  // (columns beyond the block have vcc = wcc = 0, rows beyond it wr = vr = 0)
+            const T upd = c_add(c_mul(wr[q], vcc), c_mul(vr[q], wcc));
+            A[k][q] = c_sub(A[k][q], valid ? upd : zero_el<T>());
+          }
+        }
+      }
+      // the first column of B is the next reflector's input (wave 0 holds column 0)
+      if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+          const int r = ln + 64 * q;
+          Lv2[r] = (r >= nh && r < rows) ? A[0][q] : zero_el<T>();
+        }
+      }
+      __syncthreads();
+      // ---- P4: the reflector of the first column of B (in place in v2x) ------------------------------------------------
+      if (wave == 0) {
+        T tau2 = zero_el<T>(), beta = m > 0 ? Lv2[nh] : zero_el<T>();
+        if (m > 1)
+          wave_larfg(Lv2 + nh, m, lane, tau2, beta);
+        else if (m == 1 && lane == 0)
+          Lv2[nh] = zero_el<T>();  // (no reflector: the element stays as it is)
+        if (lane == 0) {
+          Lsc[1] = tau2;
+          Lsc[3] = beta;
+        }
+      }
+      __syncthreads();
+      // ---- P5/6: A -= v2x (conj(tau2) conj(A_c^H v2)) on the columns of B but the first, then all stores ------------------
+      {
+        const T ctau2 = c_conj(Lsc[1]);
+        const T beta = Lsc[3];
+        T v2r[QN];
+#pragma unroll
+        for (int q = 0; q < QN; ++q)
+          v2r[q] = Lv2[ln + 64 * q];
+        asm volatile("" : "+v"(ln));
+        const unsigned base_st = (unsigned) ((j * ldb + ln) * (long) sizeof(T));
+#pragma unroll
+        for (int k = 0; k < CPW; ++k) {
+          const int cc = wave + NW * k;
+          T part = zero_el<T>();
+#pragma unroll
+          for (int q = 0; q < QN; ++q)
+            part = c_add(part, c_cmul(A[k][q], v2r[q]));
+          part = wave_sum_t(part);
+          const T f = c_mul(ctau2, c_conj(part));
+#pragma unroll
+          for (int q = 0; q < QN; ++q) {
+            const int r = ln + 64 * q;
+            T v = c_sub(A[k][q], c_mul(v2r[q], f));
+            if (wave == 0 && k == 0 && r >= nh) {
+              // first column of B: beta on top, exact zeros below (m == 1: the element itself, beta holds it)
+              v = r == nh ? beta : zero_el<T>();
+            }
+            const bool valid = cc < nh && r >= cc && r < rows;
+            buf_store_sc1<T>(rsrc, valid ? base_st + (unsigned) (64 * q * (int) sizeof(T)) : kOob,
+                             (unsigned) (cc * (ldb - 1) * (int) sizeof(T)), v);
+          }
+        }
+      }
+      __syncthreads();
+      if (m > 1) {
+        for (int r = tid; r < kB2tExt; r += NT)
+          Lv[r] = r < m ? Lv2[nh + r] : zero_el<T>();
+        if (tid == 0)
+          Lsc[0] = Lsc[1];
+      }
+      publish((unsigned) step + 1u);
+      __syncthreads();
+    }
+    if (!ok) {
+      if (tid == 0) {
+        __hip_atomic_store(p.failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicCAS(p.info, 0, kInfoSchedulingFailure);
+      }
+    }
+    publish(kB2tDone);
+    __syncthreads();
+  }
+}
+template <class T, int NT>
+size_t b2t_reg_lds_bytes() {
+  return ((size_t) 4 * kB2tExt + kB2tRegBand + (size_t) (NT / 64) * kB2tExt + 8) * sizeof(T) + 16;
+}
+
 // ======================================================================================= reflector blocks
 // one workgroup per block (ib, jb): well-formed 2 b x b image + taus
 template <class T>
@@ -628,6 +944,19 @@ void launch_band_to_tridiag(T* band, long n, int b, T* vout, long ldv, unsigned*
     (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&b2t_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int) b2t_lds_bytes<T>(kB2tMaxBand));
     attr_set[ti] = true;
+  }
+  static const bool use_reg = [] {
+    const char* e = std::getenv("DLAF_MI355X_B2T_KERNEL");  // "generic": the kernel that re-reads the block per phase
+    return !(e && e[0] == 'g');
+  }();
+  if constexpr (sizeof(T) <= 8) {
+    if (use_reg && b <= kB2tRegBand) {
+      // 64 elements of the block per thread: 128 registers for 8-byte types (complex double keeps the generic kernel)
+      constexpr int NT = 512;
+      const size_t reg_lds = b2t_reg_lds_bytes<T, NT>();
+      hipLaunchKernelGGL((b2t_reg_kernel<T, NT>), dim3(g), dim3(NT), reg_lds, stream, a);
+      return;
+    }
   }
   hipLaunchKernelGGL((b2t_kernel<T>), dim3(g), dim3(kB2tThreads), lds, stream, a);
 }

@@ -89,6 +89,8 @@ int band_to_tridiag_device(DeviceMatrix<T>& A, int band, real_t<T>* d, real_t<T>
     return 0;
   StageTimer timer(s);
   T* bandm = ealloc<T>((size_t) (n + 2) * 2 * band);
+  // (the two columns of slack behind the matrix are read, never used: they must hold numbers)
+  DLAF_HIP_CHECK(hipMemsetAsync(bandm + (size_t) n * 2 * band, 0, (size_t) 2 * 2 * band * sizeof(T), s));
   unsigned* sync = ealloc<unsigned>(b2t_sync_words(n));
   launch_band_extract(A.tiles, A.ltr, A.nb, A.rows.P, A.rows.shift(), A.cols.P, A.cols.shift(), n, band, bandm, s);
   if (dist)
