@@ -319,6 +319,69 @@ def main():
                     print(f"[dist_worker] bt_reduction_to_band FAILED {t} n={n} nb={nb} band={band} k={k} grid {nprow}x{npcol}: "
                           f"max diff {np.abs(gotc - refc).max()} tol {tolc}", flush=True)
                 ok &= goodc
+        # band_to_tridiagonal on the grid (test_band_to_tridiag.cpp:151-183: the reference's reconstruction check, a
+        # non-zero source rank): every rank ends up with the whole tridiagonal matrix and reflectors, bit-identical
+        from oracle import tridiag as td
+        for t, n, nb, band, src in [("d", 18, 4, 4, 1), ("z", 34, 6, 6, 0), ("d", 37, 9, 3, 1), ("c", 16, 12, 6, 0),
+                                    ("d", 300, 32, 16, 1), ("z", 260, 64, 32, 1)]:
+            dt = oracle.DTYPES[t]
+            sr, sc = (max(0, nprow - 1), min(1, npcol - 1)) if src else (0, 0)
+            a0 = rb.random_hermitian(n, dt, seed=500 + n, banded=band)
+            la = np.asfortranarray(oracle.scatter(a0, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
+            d_, e_, v_ = dlaf.band_to_tridiagonal(grid, la, nb, band, sr, sc, n=n)
+            allr = [None] * dist.get_world_size()
+            dist.all_gather_object(allr, (d_, e_, v_))
+            good = all(np.array_equal(allr[0][0], x[0]) and np.array_equal(allr[0][1], x[1]) and
+                       np.array_equal(allr[0][2], x[2]) for x in allr)
+            if rank == 0:
+                okc, diff, bar = td.check_band_to_tridiag(a0, band, d_, e_, v_)
+                good &= bool(okc)
+                if not good:
+                    print(f"[dist_worker] band_to_tridiagonal FAILED {t} n={n} nb={nb} band={band} grid {nprow}x{npcol}: {diff} {bar}",
+                          flush=True)
+            ok &= bool(good)
+        # hermitian_eigensolver / hermitian_generalized_eigensolver on the grid through the reference's C entries
+        # (test_eigensolver.cpp, test_gen_eigensolver.cpp: testEigensolverCorrectness on the gathered results; A and the
+        # eigenvector matrix with different source columns)
+        for t, n, nb, src in [("d", 34, 8, 1), ("z", 64, 16, 0), ("s", 32, 5, 1), ("d", 300, 32, 1), ("z", 260, 64, 0),
+                              ("d", 1100, 256, 1), ("d", 5, 8, 0)]:
+            dt = oracle.DTYPES[t]
+            sr, sc = (max(0, nprow - 1), min(1, npcol - 1)) if src else (0, 0)
+            zsc = 0 if src else min(1, npcol - 1)
+            a0 = rb.random_hermitian(n, dt, seed=700 + n)
+            la = np.asfortranarray(oracle.scatter(a0, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
+            zshape = grid.local_shape(n, nb, sr, zsc)
+            w, lz = dlaf.hermitian_eigensolver(grid, "L", la, nb, sr, sc, n=n, z_jsrc=zsc, z_shape=zshape)
+            z = gather_global(lz, grid, n, nb, sr, zsc, oracle)
+            allw = [None] * dist.get_world_size()
+            dist.all_gather_object(allw, w)
+            good = all(np.array_equal(allw[0], x) for x in allw)
+            if rank == 0:
+                res = td.check_eigensolver(a0, w, z)
+                good &= res["sorted"] and res["orth"] <= res["orth_bar"] and res["residual_ok"]
+                if not good:
+                    print(f"[dist_worker] hermitian_eigensolver FAILED {t} n={n} nb={nb} grid {nprow}x{npcol}: {res}", flush=True)
+            ok &= bool(good)
+        for t, n, nb in [("d", 64, 16), ("z", 130, 32)]:
+            dt = oracle.DTYPES[t]
+            sr, sc = max(0, nprow - 1), min(1, npcol - 1)
+            a0 = rb.random_hermitian(n, dt, seed=900 + n)
+            b0 = rb.random_hermitian(n, dt, seed=901 + n)
+            b0 = np.asfortranarray((b0 @ b0.conj().T / n + 2 * np.eye(n)).astype(dt))
+            la = np.asfortranarray(oracle.scatter(a0, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
+            lb = np.asfortranarray(oracle.scatter(b0, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
+            w, lz = dlaf.hermitian_generalized_eigensolver(grid, "L", la, lb, nb, sr, sc, n=n)
+            z = gather_global(lz, grid, n, nb, sr, sc, oracle)
+            if rank == 0:
+                err = td.error_of(dt)
+                g_ = z.conj().T @ b0 @ z
+                r_ = a0 @ z - (b0 @ z) * w[None, :]
+                good = bool(np.all(np.diff(w) >= 0)) and np.abs(g_ - np.eye(n)).max() <= 10 * n * err * np.abs(b0).max() and \
+                    np.abs(r_).max() <= 10 * n * err * max(1.0, np.abs(a0).max() * np.abs(w).max())
+                if not good:
+                    print(f"[dist_worker] generalized eigensolver FAILED {t} n={n} nb={nb} grid {nprow}x{npcol}: "
+                          f"{np.abs(g_ - np.eye(n)).max()} {np.abs(r_).max()}", flush=True)
+                ok &= bool(good)
         # p?potrf -> p?potrs on resident matrices over the grid (no host staging between the factorization and the
         # two solves), and one resident solve per side against the oracle
         for t, uplo, n, nrhs, nb in [("d", "L", 300, 90, 32), ("z", "U", 200, 70, 32)]:
