@@ -48,6 +48,8 @@ def parse():
     p.add_argument("--no-trsm-profile", action="store_true", help="skip the stand-alone panel-TRSM timing (PMC passes: only the factorization's own launches are counted)")
     p.add_argument("--no-red2band", action="store_true",
                    help="skip the extra (untimed-for-the-metric) reduction_to_band line at N = 1")
+    p.add_argument("--no-eigensolver", action="store_true",
+                   help="skip the extra (untimed-for-the-metric) whole-eigensolver line at N = 1")
     p.add_argument("--r2b-n", type=int, default=20480)
     p.add_argument("--r2b-nb", type=int, default=512)
     p.add_argument("--transport", default="rccl", choices=["rccl", "host"],
@@ -106,6 +108,45 @@ def red2band_line(dlaf, grid, n, nb, runs=2):
             "value": round(tf, 3), "unit": "TFlop/s", "ms": round(best_ms, 2), "runs": runs,
             "flop_model": "2 (2/3 n^3 - n^2 nb)  (miniapp_reduction_to_band.cpp:163-168)",
             "fraction_of_fp64_mfma_peak": round(tf / PEAK_FP64_MFMA_TFLOPS, 4)}
+
+
+def eigensolver_line(dlaf, grid, n, nb, runs=1):
+    """BASELINE configs[4] on one GPU: the whole Hermitian eigensolver (reduction_to_band, band_to_tridiagonal,
+    tridiagonal_eigensolver, bt_band_to_tridiagonal, bt_reduction_to_band; eigensolver/impl.h:38-55) through the
+    reference's C entry dlaf_symmetric_eigensolver_d on a random symmetric matrix.  Reported: the sum of the per-stage
+    device times (HIP events; operands resident, like the window of miniapp_eigensolver.cpp:150-165 whose mirrors are
+    created outside the timer), the stages, the wall time of the host-array entry (PCIe staging included) and a
+    sampled check of the result.  An extra line next to the metric, not part of it."""
+    import time as _t
+    a0 = np.zeros((n, n), dtype=np.float64, order="F")
+    dlaf.set_random_hermitian_positive_definite(grid, a0, n, nb)
+    a0[np.arange(n), np.arange(n)] -= 2.0 * n
+    names = ["reduction_to_band", "band_to_tridiagonal", "tridiagonal_eigensolver", "bt_band_to_tridiagonal",
+             "bt_reduction_to_band"]
+    best = None
+    for r in range(runs + 1):
+        a = a0.copy(order="F")
+        t0 = _t.time()
+        w, z = dlaf.hermitian_eigensolver(grid, "L", a, nb)
+        wall = _t.time() - t0
+        ms = dlaf.eigensolver_profile()
+        del a
+        if r > 0 or runs == 0:
+            if best is None or sum(ms) < sum(best[0]):
+                best = (ms, wall)
+    ms, wall = best
+    cols = np.unique(np.concatenate([np.arange(0, n, max(1, n // 16)), [n - 1]]))
+    zc = z[:, cols]
+    az = np.tril(a0) @ zc + np.tril(a0, -1).T @ zc
+    res = float(np.abs(az - zc * w[cols][None, :]).max())
+    orth = float(np.abs(zc.T @ zc - np.eye(len(cols))).max())
+    err = 2 * float(np.finfo(np.float64).eps)
+    return {"workload": f"hermitian_eigensolver_d N={n} nb={nb} band={dlaf.get_band_size(nb)} (BASELINE configs[4], 1 GPU)",
+            "value": round(sum(ms) / 1e3, 4), "unit": "s", "higher_is_better": False,
+            "stages_ms": {k: round(v, 1) for k, v in zip(names, ms)},
+            "wall_s_host_arrays_incl_pcie": round(wall, 3), "runs": runs,
+            "sampled_check": {"columns": int(len(cols)), "max|A z - w z|": res, "bar_2_n_err_wmax": 2 * n * err * float(np.abs(w).max()),
+                              "max|Z^T Z - I|": orth, "bar_10_n_err": 10 * n * err, "sorted": bool(np.all(np.diff(w) >= 0))}}
 
 
 def host_grid(dlaf, dist, torch, nprow, npcol):
@@ -309,6 +350,11 @@ def main():
                 line["reduction_to_band"] = red2band_line(dlaf, grid, args.r2b_n, args.r2b_nb)
             except Exception as e:  # an extra line: it must never take the metric down with it
                 line["reduction_to_band"] = {"value": None, "error": repr(e)}
+            if not args.no_eigensolver:
+                try:
+                    line["eigensolver"] = eigensolver_line(dlaf, grid, args.r2b_n, args.r2b_nb)
+                except Exception as e:
+                    line["eigensolver"] = {"value": None, "error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline(args)

@@ -83,7 +83,9 @@ struct GemmMap {
   int kchunk;
 };
 
-template <class T>
+// MA / MB >= 0: the slab modes of the operands fixed at compile time (the launcher checked alignment and K % BK): only
+// that loader is compiled in, k-contiguous operands go through the conflict-free transposed LDS image
+template <class T, int MA = -1, int MB = -1>
 __global__ __launch_bounds__(GenCfg<T>::type::THREADS, 2) void gemm_kernel(GemmArgs<T> p, GemmMap mp) {
   using Cfg = typename GenCfg<T>::type;
   using R = real_t<T>;
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(GenCfg<T>::type::THREADS, 2) void gemm_kernel(GemmA
   Acc<Cfg> acc;
   acc.clear();
   if (kk > 0)
-    gemm_acc<Cfg, T>(da, mrows, db, ncols, kk, lds, acc);
+    gemm_acc<Cfg, T, MA, MB>(da, mrows, db, ncols, kk, lds, acc);
   if (mp.KS == 1) {
     const bool has_beta = !el_is_zero(p.beta);
     acc_foreach<Cfg, T>(acc, [&](int m, int n, const T& v) {
@@ -928,8 +930,33 @@ void launch_gemm(const GemmArgs<T>& a, hipStream_t stream) {
   mp.kchunk = kchunk;
   if (mp.KS > 1)
     mp.KS = (a.K + kchunk - 1) / kchunk;
-  hipLaunchKernelGGL((gemm_kernel<T>), dim3((unsigned) (mp.MB * mp.NB * mp.KS), (unsigned) std::max(a.batch, 1)),
-                     dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, a, mp);
+  // fixed-mode instantiation when every block of the product may take the 16-byte loaders
+  constexpr int VE = (16 / (int) sizeof(T)) > 0 ? (16 / (int) sizeof(T)) : 1;
+  auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+  auto ld16 = [](long ld) { return (ld * (long) sizeof(T)) % 16 == 0; };
+  static const bool allow_fixed = [] {
+    const char* e = std::getenv("DLAF_MI355X_GEMM_FIXED");
+    return e ? std::atoi(e) != 0 : true;
+  }();
+  const bool kfull = a.K > 0 && a.K % Cfg::BK == 0 && kchunk % Cfg::BK == 0;
+  const bool batch_ok = a.batch <= 1 || (ld16(a.sa) && ld16(a.sb));
+  const bool a_ok = al16(a.a) && ld16(a.lda) && (a.opa != 'N' || a.M % VE == 0);
+  const bool b_ok = al16(a.b) && ld16(a.ldb) && (a.opb == 'N' || a.N % VE == 0);
+  const dim3 grid((unsigned) (mp.MB * mp.NB * mp.KS), (unsigned) std::max(a.batch, 1));
+  if (allow_fixed && kfull && batch_ok && a_ok && b_ok) {
+    const int ma = a.opa == 'N' ? 0 : 1, mb = a.opb == 'N' ? 1 : 0;
+    if (ma == 0 && mb == 0)
+      hipLaunchKernelGGL((gemm_kernel<T, 0, 0>), grid, dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, a, mp);
+    else if (ma == 0 && mb == 1)
+      hipLaunchKernelGGL((gemm_kernel<T, 0, 1>), grid, dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, a, mp);
+    else if (ma == 1 && mb == 0)
+      hipLaunchKernelGGL((gemm_kernel<T, 1, 0>), grid, dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, a, mp);
+    else
+      hipLaunchKernelGGL((gemm_kernel<T, 1, 1>), grid, dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, a, mp);
+  }
+  else {
+    hipLaunchKernelGGL((gemm_kernel<T>), grid, dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, a, mp);
+  }
   if (mp.KS > 1)
     hipLaunchKernelGGL((gemm_reduce_kernel<T>), dim3((unsigned) ((Cfg::BM * Cfg::BN + kThreads - 1) / kThreads), (unsigned) (mp.MB * mp.NB)),
                        dim3(kThreads), 0, stream, a, mp);
@@ -1181,6 +1208,14 @@ template <class T>
 static void band_init_one() {
   using Cfg = typename GenCfg<T>::type;
   (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             Cfg::LDS_BYTES);
+  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             Cfg::LDS_BYTES);
+  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             Cfg::LDS_BYTES);
+  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             Cfg::LDS_BYTES);
+  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              Cfg::LDS_BYTES);
   (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_panel_kernel<T, 0>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);

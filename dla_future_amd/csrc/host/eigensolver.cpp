@@ -58,6 +58,20 @@ struct StageTimer {
 };
 }  // namespace
 
+// E of the back-transformation band <- tridiagonal: leading dimension a multiple of 16 bytes, element 1 (not 0) on a
+// 16-byte boundary
+long bt_aligned_ld(long n) {
+  return ((n + 1) / 2) * 2;
+}
+template <class T>
+T* bt_aligned_base(T* alloc) {
+  // hipMalloc returns 256-byte aligned memory: one element in front for 8-byte types, none for 16-byte ones, three for
+  // 4-byte ones
+  if (sizeof(T) == 16)
+    return alloc;
+  return alloc + (16 / sizeof(T) - 1);
+}
+
 void eigensolver_last_profile(double ms[5]) {
   for (int i = 0; i < 5; ++i)
     ms[i] = g_stage_ms[i];
@@ -296,19 +310,23 @@ int bt_band_to_tridiag_host(long n, int band, const T* v, long ldv, T* e, long l
   hipStream_t s;
   DLAF_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   T* dv = ealloc<T>((size_t) n * n);
-  T* de = ealloc<T>((size_t) n * ncols);
+  // row 1 of E on a 16-byte boundary, even leading dimension: the row blocks the reflector blocks act on start at the
+  // rows 1 + i b, and the k-contiguous operand loader of the general product wants them aligned
+  const long ldd = bt_aligned_ld(n);
+  T* de_alloc = ealloc<T>((size_t) ldd * ncols + 4);
+  T* de = bt_aligned_base(de_alloc);
   DLAF_HIP_CHECK(hipMemcpy2DAsync(dv, (size_t) n * sizeof(T), v, (size_t) ldv * sizeof(T), (size_t) n * sizeof(T), (size_t) n,
                                   hipMemcpyHostToDevice, s));
-  DLAF_HIP_CHECK(hipMemcpy2DAsync(de, (size_t) n * sizeof(T), e, (size_t) lde * sizeof(T), (size_t) n * sizeof(T),
+  DLAF_HIP_CHECK(hipMemcpy2DAsync(de, (size_t) ldd * sizeof(T), e, (size_t) lde * sizeof(T), (size_t) n * sizeof(T),
                                   (size_t) ncols, hipMemcpyHostToDevice, s));
   StageTimer timer(s);
-  const int r = bt_band_to_tridiag_device(n, band, dv, n, de, n, ncols, s);
+  const int r = bt_band_to_tridiag_device(n, band, dv, n, de, ldd, ncols, s);
   g_stage_ms[3] = timer.stop();
-  DLAF_HIP_CHECK(hipMemcpy2DAsync(e, (size_t) lde * sizeof(T), de, (size_t) n * sizeof(T), (size_t) n * sizeof(T),
+  DLAF_HIP_CHECK(hipMemcpy2DAsync(e, (size_t) lde * sizeof(T), de, (size_t) ldd * sizeof(T), (size_t) n * sizeof(T),
                                   (size_t) ncols, hipMemcpyDeviceToHost, s));
   DLAF_HIP_CHECK(hipStreamSynchronize(s));
   DLAF_HIP_CHECK(hipFree(dv));
-  DLAF_HIP_CHECK(hipFree(de));
+  DLAF_HIP_CHECK(hipFree(de_alloc));
   DLAF_HIP_CHECK(hipStreamDestroy(s));
   return r;
 }
@@ -352,19 +370,21 @@ int hermitian_eigensolver_device(DeviceMatrix<T>& A, real_t<T>* w_host, GeneralM
   DLAF_HIP_CHECK(hipMemcpyAsync(w_host, wd, (size_t) n * sizeof(R), hipMemcpyDeviceToHost, s));
   // the columns of this process column, all rows (the back-transformation mixes rows, never columns)
   const long ncl = C.cols.local_size();
-  T* el = ealloc<T>((size_t) n * std::max<long>(ncl, 1));
-  launch_cols_gather_cast<R, T>(zr, n, n, nb, C.cols.P, C.cols.shift(), ncl, el, n, s);
+  const long lde = bt_aligned_ld(n);
+  T* el_alloc = ealloc<T>((size_t) lde * std::max<long>(ncl, 1) + 4);
+  T* el = bt_aligned_base(el_alloc);
+  launch_cols_gather_cast<R, T>(zr, n, n, nb, C.cols.P, C.cols.shift(), ncl, el, lde, s);
   {
     StageTimer t(s);
-    bt_band_to_tridiag_device(n, band, v, n, el, n, ncl, s);
+    bt_band_to_tridiag_device(n, band, v, n, el, lde, ncl, s);
     g_stage_ms[3] = t.stop();
   }
-  launch_rows_to_tiles(el, n, n, ncl, nb, C.rows.P, C.rows.shift(), C.ltr, C.ltc, C.tiles, s);
+  launch_rows_to_tiles(el, lde, n, ncl, nb, C.rows.P, C.rows.shift(), C.ltr, C.ltc, C.tiles, s);
   DLAF_HIP_CHECK(hipStreamSynchronize(s));
   for (R* q : {d, e, wd, zr})
     DLAF_HIP_CHECK(hipFree(q));
   DLAF_HIP_CHECK(hipFree(v));
-  DLAF_HIP_CHECK(hipFree(el));
+  DLAF_HIP_CHECK(hipFree(el_alloc));
   info = bt_reduction_to_band_device(band, C, A, taus.data());
   {
     double ms = 0, fl = 0;
