@@ -28,6 +28,8 @@
 #include <vector>
 
 #include <dlaf_c/desc.h>
+#include <dlaf_c/eigensolver/eigensolver.h>
+#include <dlaf_c/eigensolver/gen_eigensolver.h>
 #include <dlaf_c/factorization/cholesky.h>
 #include <dlaf_c/grid.h>
 #include <dlaf_c/init.h>
@@ -35,7 +37,18 @@
 
 namespace dlaf {
 
-using SizeType = std::ptrdiff_t;  // include/dlaf/types.h:25
+using SizeType = std::ptrdiff_t;
+// dlaf::BaseType (include/dlaf/types.h): the real type behind an element type
+template <class T>
+struct BaseTypeOf {
+  using type = T;
+};
+template <class R>
+struct BaseTypeOf<std::complex<R>> {
+  using type = R;
+};
+template <class T>
+using BaseType = typename BaseTypeOf<T>::type;  // include/dlaf/types.h:25
 
 enum class Backend { MC, GPU, Default = GPU };   // types.h:31-37 (MC has no implementation in this library)
 enum class Device { CPU, GPU, Default = GPU };   // types.h:39-45
@@ -506,6 +519,68 @@ void bt_reduction_to_band(comm::CommunicatorGrid& grid, SizeType band_size, Matr
     dlaf::internal::fail("bt_reduction_to_band");
 }
 }  // namespace eigensolver::internal
+
+// include/dlaf/eigensolver/eigensolver.h:56-190 and gen_eigensolver.h: host-resident matrices, as
+// the reference's C entries take them.  eigenvalues: all n on every process (the reference returns a local N x 1 Matrix).
+namespace internal {
+template <class T>
+DLAF_descriptor descriptor_of(const Matrix<T, Device::CPU>& m) {
+  const auto& d = m.distribution();
+  return DLAF_descriptor{(int) d.size().rows(), (int) d.size().cols(), (int) d.block_size().rows(),
+                         (int) d.block_size().cols(), (int) d.source_rank_index().row(),
+                         (int) d.source_rank_index().col(), 0, 0, (int) m.ld()};
+}
+}  // namespace internal
+template <Backend B, class T>
+void hermitian_eigensolver(comm::CommunicatorGrid& grid, blas::Uplo uplo, Matrix<T, Device::CPU>& mat,
+                           std::vector<BaseType<T>>& eigenvalues, Matrix<T, Device::CPU>& eigenvectors) {
+  static_assert(B == Backend::GPU, "this library has no CPU backend");
+  const char u = uplo == blas::Uplo::Lower ? 'L' : 'U';
+  eigenvalues.assign((size_t) mat.size().rows(), BaseType<T>(0));
+  BaseType<T> dummy{};
+  BaseType<T>* w = eigenvalues.empty() ? &dummy : eigenvalues.data();
+  const DLAF_descriptor da = internal::descriptor_of(mat), dz = internal::descriptor_of(eigenvectors);
+  int r;
+  if constexpr (std::is_same_v<T, float>)
+    r = dlaf_symmetric_eigensolver_s(grid.context(), u, mat.ptr(), da, w, eigenvectors.ptr(), dz);
+  else if constexpr (std::is_same_v<T, double>)
+    r = dlaf_symmetric_eigensolver_d(grid.context(), u, mat.ptr(), da, w, eigenvectors.ptr(), dz);
+  else if constexpr (std::is_same_v<T, std::complex<float>>)
+    r = dlaf_hermitian_eigensolver_c(grid.context(), u, reinterpret_cast<dlaf_complex_c*>(mat.ptr()), da, w,
+                                     reinterpret_cast<dlaf_complex_c*>(eigenvectors.ptr()), dz);
+  else
+    r = dlaf_hermitian_eigensolver_z(grid.context(), u, reinterpret_cast<dlaf_complex_z*>(mat.ptr()), da, w,
+                                     reinterpret_cast<dlaf_complex_z*>(eigenvectors.ptr()), dz);
+  if (r != 0)
+    dlaf::internal::fail("hermitian_eigensolver");
+}
+template <Backend B, class T>
+void hermitian_generalized_eigensolver(comm::CommunicatorGrid& grid, blas::Uplo uplo, Matrix<T, Device::CPU>& mat_a,
+                                       Matrix<T, Device::CPU>& mat_b, std::vector<BaseType<T>>& eigenvalues,
+                                       Matrix<T, Device::CPU>& eigenvectors) {
+  static_assert(B == Backend::GPU, "this library has no CPU backend");
+  const char u = uplo == blas::Uplo::Lower ? 'L' : 'U';
+  eigenvalues.assign((size_t) mat_a.size().rows(), BaseType<T>(0));
+  BaseType<T> dummy{};
+  BaseType<T>* w = eigenvalues.empty() ? &dummy : eigenvalues.data();
+  const DLAF_descriptor da = internal::descriptor_of(mat_a), db = internal::descriptor_of(mat_b),
+                        dz = internal::descriptor_of(eigenvectors);
+  int r;
+  if constexpr (std::is_same_v<T, float>)
+    r = dlaf_symmetric_generalized_eigensolver_s(grid.context(), u, mat_a.ptr(), da, mat_b.ptr(), db, w, eigenvectors.ptr(), dz);
+  else if constexpr (std::is_same_v<T, double>)
+    r = dlaf_symmetric_generalized_eigensolver_d(grid.context(), u, mat_a.ptr(), da, mat_b.ptr(), db, w, eigenvectors.ptr(), dz);
+  else if constexpr (std::is_same_v<T, std::complex<float>>)
+    r = dlaf_hermitian_generalized_eigensolver_c(grid.context(), u, reinterpret_cast<dlaf_complex_c*>(mat_a.ptr()), da,
+                                                 reinterpret_cast<dlaf_complex_c*>(mat_b.ptr()), db, w,
+                                                 reinterpret_cast<dlaf_complex_c*>(eigenvectors.ptr()), dz);
+  else
+    r = dlaf_hermitian_generalized_eigensolver_z(grid.context(), u, reinterpret_cast<dlaf_complex_z*>(mat_a.ptr()), da,
+                                                 reinterpret_cast<dlaf_complex_z*>(mat_b.ptr()), db, w,
+                                                 reinterpret_cast<dlaf_complex_z*>(eigenvectors.ptr()), dz);
+  if (r != 0)
+    dlaf::internal::fail("hermitian_generalized_eigensolver");
+}
 
 // include/dlaf/init.h: the library needs no runtime arguments; initialize / finalize are idempotent
 inline void initialize(int argc = 0, const char** argv = nullptr) { dlaf_initialize(argc, argv, 0, nullptr); }

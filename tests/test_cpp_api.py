@@ -63,6 +63,7 @@ def test_miniapp_compiles():
     assert os.path.exists(build_miniapp(name="miniapp_triangular_solver"))
     assert os.path.exists(build_miniapp(name="miniapp_gen_to_std"))
     assert os.path.exists(build_miniapp(name="miniapp_reduction_to_band"))
+    assert os.path.exists(build_miniapp(name="miniapp_eigensolver"))
 
 
 def check_miniapp_output(out, nruns, nchecks):
@@ -144,3 +145,18 @@ def test_miniapp_reduction_to_band():
         assert len(re.findall(r"^\[\d+\] [0-9.e+-]+s [0-9.e+-]+GFlop/s %s \(1500, 1500\) \(128, 128\) %s \(1, 1\) 1 GPU" % (tp, band),
                               r.stdout, flags=re.M)) == 2, r.stdout
         assert r.stdout.count("CSVData-2, run, ") == 2 and "band_size, " + band in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+def test_miniapp_eigensolver():
+    """miniapp_eigensolver.cpp: the reference's options and result lines, its checker (--check-result) on one process."""
+    import re
+    exe = build_miniapp(name="miniapp_eigensolver")
+    for tp in ("d", "z"):
+        r = subprocess.run([exe, "--matrix-size", "700", "--block-size", "128", "--type", tp, "--nruns", "2", "--check-result", "last",
+                            "--csv"], cwd=ROOT, capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, DLAF_MI355X_DEVICE="0"))
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        assert len(re.findall(r"^\[\d+\] [0-9.e+-]+s %s \(700, 700\) \(128, 128\) \(1, 1\) 1 GPU" % tp, r.stdout, flags=re.M)) == 2, r.stdout
+        assert r.stdout.count("Check: OK") == 1 and "Check: ERROR" not in r.stdout, r.stdout
+        assert r.stdout.count("CSVData-2, run, ") == 2, r.stdout
