@@ -504,7 +504,76 @@ __device__ __forceinline__ void buf_store_sc1(__amdgpu_buffer_rsrc_t rsrc, unsig
   }
 }
 
-template <class T, int NT>
+// Sums of 16 values per lane over the 64 lanes of a wave in 17 lane exchanges instead of 16 x 6: at every stage a
+// lane keeps half of its values and sends the other half to its partner (lane ^ 32, 16, 8, 4), then two plain stages.
+// On return lane l holds the total of value index ((l >> 5) & 1) * 8 + ((l >> 4) & 1) * 4 + ((l >> 3) & 1) * 2 + ((l >> 2) & 1).
+template <class T>
+__device__ __forceinline__ T shfl_xor_t(const T& v, int mask) {
+  if constexpr (TypeInfo<T>::is_complex)
+    return T{__shfl_xor(v.re, mask), __shfl_xor(v.im, mask)};
+  else
+    return __shfl_xor(v, mask);
+}
+template <class T>
+__device__ __forceinline__ T wave_reduce16(const T (&v)[16], int lane) {
+  T a[8], b4[4], c2[2];
+  const bool h5 = (lane & 32) != 0, h4 = (lane & 16) != 0, h3 = (lane & 8) != 0, h2 = (lane & 4) != 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const T mine = h5 ? v[8 + i] : v[i];
+    const T theirs = h5 ? v[i] : v[8 + i];
+    a[i] = c_add(mine, shfl_xor_t(theirs, 32));
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const T mine = h4 ? a[4 + i] : a[i];
+    const T theirs = h4 ? a[i] : a[4 + i];
+    b4[i] = c_add(mine, shfl_xor_t(theirs, 16));
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const T mine = h3 ? b4[2 + i] : b4[i];
+    const T theirs = h3 ? b4[i] : b4[2 + i];
+    c2[i] = c_add(mine, shfl_xor_t(theirs, 8));
+  }
+  T r = c_add(h2 ? c2[1] : c2[0], shfl_xor_t(h2 ? c2[0] : c2[1], 4));
+  r = c_add(r, shfl_xor_t(r, 2));
+  r = c_add(r, shfl_xor_t(r, 1));
+  return r;
+}
+// the same for 8 values (10 exchanges): lane l ends with the total of index ((l >> 5) & 1) * 4 + ((l >> 4) & 1) * 2 + ((l >> 3) & 1)
+template <class T>
+__device__ __forceinline__ T wave_reduce8(const T (&v)[8], int lane) {
+  T b4[4], c2[2];
+  const bool h5 = (lane & 32) != 0, h4 = (lane & 16) != 0, h3 = (lane & 8) != 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const T mine = h5 ? v[4 + i] : v[i];
+    const T theirs = h5 ? v[i] : v[4 + i];
+    b4[i] = c_add(mine, shfl_xor_t(theirs, 32));
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const T mine = h4 ? b4[2 + i] : b4[i];
+    const T theirs = h4 ? b4[i] : b4[2 + i];
+    c2[i] = c_add(mine, shfl_xor_t(theirs, 16));
+  }
+  T r = c_add(h3 ? c2[1] : c2[0], shfl_xor_t(h3 ? c2[0] : c2[1], 8));
+  r = c_add(r, shfl_xor_t(r, 4));
+  r = c_add(r, shfl_xor_t(r, 2));
+  r = c_add(r, shfl_xor_t(r, 1));
+  return r;
+}
+__device__ __forceinline__ int wave_reduce8_index(int lane) {
+  return ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+}
+__device__ __forceinline__ int wave_reduce16_index(int lane) {
+  return ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+}
+
+// EARLY (band == kB2tRegBand): the loads of a step are issued before the wait for the predecessor's latest step, its
+// last column re-read after it (see the load section)
+template <class T, int NT, bool EARLY>
 __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
   using R = real_t<T>;
   constexpr int NW = NT / 64;
@@ -520,7 +589,8 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
   T* Lcs = Lv2 + kB2tExt;                 // per column: (strictly lower D)^H v
   T* Lzw = Lcs + kB2tRegBand;             // NW x kB2tExt partial products A v
   T* Lsc = Lzw + (size_t) NW * kB2tExt;   // [0] tau, [1] tau2, [2] alpha, [3] beta
-  unsigned* Lslot = reinterpret_cast<unsigned*>(Lsc + 4);
+  T* Lred = Lsc + 4;                      // NW x CPW: column totals of a wave's reductions
+  unsigned* Lslot = reinterpret_cast<unsigned*>(Lred + NW * CPW);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long n = p.n;
@@ -597,18 +667,33 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
         for (int i = tid; i < nh; i += NT)
           dst[i] = i == 0 ? tau : Lv[i];
       }
-      ok = wait_prev((unsigned) step + 2u);
-      if (!ok)
-        break;
       // (the lane index is made opaque per step: otherwise the per-element masks and offsets are hoisted out of the
       //  step loop and kept alive across it)
       int ln = lane;
       asm volatile("" : "+v"(ln));
-      // ---- the block: all loads of the step; element (r, cc) lives at band[(j + cc) ldb + r - cc] ------------------------
+      // ---- the block: all loads of the step; element (r, cc) lives at band[(j + cc) ldb + r - cc].  Of the block only
+      //      its last column (cc = b - 1, rows from b - 1 on: the first column of the predecessor's NEXT diagonal block) is
+      //      still being written by sweep s - 1 at its step + 1; everything else was final when the predecessor published
+      //      step + 1 finished steps -- which this sweep already waited for at its previous step (or at the sweep start).
+      //      So all columns but that one are loaded BEFORE the wait for step + 2: their latency hides behind it.
       T A[CPW][QN];
       const unsigned base_off = (unsigned) ((j * ldb + ln) * (long) sizeof(T));
+      if constexpr (EARLY) {
 #pragma unroll
-      for (int k = 0; k < CPW; ++k) {
+        for (int k = 0; k < CPW; ++k) {
+          const int cc = wave + NW * k;
+#pragma unroll
+          for (int q = 0; q < QN; ++q)
+            A[k][q] = buf_load_sc1<T>(rsrc, base_off + (unsigned) (64 * q * (int) sizeof(T)),
+                                      (unsigned) (cc * (ldb - 1) * (int) sizeof(T)));
+        }
+      }
+      ok = wait_prev((unsigned) step + 2u);
+      if (!ok)
+        break;
+#pragma unroll
+      for (int k = EARLY ? CPW - 1 : 0; k < CPW; ++k) {
+        // (EARLY: column b - 1 = wave NW - 1, k = CPW - 1; the other waves re-read a column that was final already)
         const int cc = wave + NW * k;
 #pragma unroll
         for (int q = 0; q < QN; ++q)
@@ -622,28 +707,35 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
         zacc[q] = zero_el<T>();
       }
       // ---- P1: z = A v over the rows of both blocks, cs = strictly-lower(D)^H v -----------------------------------------
+      static_assert(CPW == 16, "wave_reduce8 x 2 / wave_reduce16");
 #pragma unroll
-      for (int k = 0; k < CPW; ++k) {
-        const int cc = wave + NW * k;
-        const T vc = Lv[cc];  // (zero beyond the reflector)
-        T part = zero_el<T>();
+      for (int half = 0; half < 2; ++half) {
+        T parts[8];
 #pragma unroll
-        for (int q = 0; q < QN; ++q) {
-          const int r = ln + 64 * q;
-          const bool valid = cc < nh && r >= cc && r < rows;
-          T a = valid ? A[k][q] : zero_el<T>();
-          if (64 * q < kB2tRegBand && r == cc)
-            a = make_el<T>(re_of(a), R(0));  // the diagonal element
-          A[k][q] = a;
-          zacc[q] = c_add(zacc[q], c_mul(a, vc));
-          if (64 * q < kB2tRegBand)
-            part = c_add(part, r == cc ? zero_el<T>() : c_cmul(a, vr[q]));
-          else
-            part = c_add(part, c_cmul(a, vr[q]));  // (rows of B: vr is zero there)
+        for (int kk = 0; kk < 8; ++kk) {
+          const int k = half * 8 + kk;
+          const int cc = wave + NW * k;
+          const T vc = Lv[cc];  // (zero beyond the reflector)
+          T part = zero_el<T>();
+#pragma unroll
+          for (int q = 0; q < QN; ++q) {
+            const int r = ln + 64 * q;
+            const bool valid = cc < nh && r >= cc && r < rows;
+            T a = valid ? A[k][q] : zero_el<T>();
+            if (64 * q < kB2tRegBand && r == cc)
+              a = make_el<T>(re_of(a), R(0));  // the diagonal element
+            A[k][q] = a;
+            zacc[q] = c_add(zacc[q], c_mul(a, vc));
+            if (64 * q < kB2tRegBand)
+              part = c_add(part, r == cc ? zero_el<T>() : c_cmul(a, vr[q]));
+            else
+              part = c_add(part, c_cmul(a, vr[q]));  // (rows of B: vr is zero there)
+          }
+          parts[kk] = part;
         }
-        part = wave_sum_t(part);
-        if (lane == 0)
-          Lcs[cc] = part;
+        const T tot = wave_reduce8(parts, lane);
+        if ((lane & 7) == 0)
+          Lcs[wave + NW * (half * 8 + wave_reduce8_index(lane))] = tot;
       }
 #pragma unroll
       for (int q = 0; q < QN; ++q)
@@ -735,15 +827,27 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
           v2r[q] = Lv2[ln + 64 * q];
         asm volatile("" : "+v"(ln));
         const unsigned base_st = (unsigned) ((j * ldb + ln) * (long) sizeof(T));
+        {
+          T parts[CPW];
+#pragma unroll
+          for (int k = 0; k < CPW; ++k) {
+            T part = zero_el<T>();
+#pragma unroll
+            for (int q = 0; q < QN; ++q)
+              part = c_add(part, c_cmul(A[k][q], v2r[q]));
+            parts[k] = part;
+          }
+          const T tot = wave_reduce16(parts, lane);
+          if ((lane & 3) == 0)
+            Lred[wave * CPW + wave_reduce16_index(lane)] = tot;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
 #pragma unroll
         for (int k = 0; k < CPW; ++k) {
           const int cc = wave + NW * k;
-          T part = zero_el<T>();
-#pragma unroll
-          for (int q = 0; q < QN; ++q)
-            part = c_add(part, c_cmul(A[k][q], v2r[q]));
-          part = wave_sum_t(part);
-          const T f = c_mul(ctau2, c_conj(part));
+          const T f = c_mul(ctau2, c_conj(Lred[wave * CPW + k]));
 #pragma unroll
           for (int q = 0; q < QN; ++q) {
             const int r = ln + 64 * q;
@@ -780,7 +884,7 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
 }
 template <class T, int NT>
 size_t b2t_reg_lds_bytes() {
-  return ((size_t) 4 * kB2tExt + kB2tRegBand + (size_t) (NT / 64) * kB2tExt + 8) * sizeof(T) + 16;
+  return ((size_t) 4 * kB2tExt + kB2tRegBand + (size_t) (NT / 64) * kB2tExt + 8 + kB2tRegBand) * sizeof(T) + 16;
 }
 
 // ======================================================================================= reflector blocks
@@ -954,7 +1058,10 @@ void launch_band_to_tridiag(T* band, long n, int b, T* vout, long ldv, unsigned*
       // 64 elements of the block per thread: 128 registers for 8-byte types (complex double keeps the generic kernel)
       constexpr int NT = 512;
       const size_t reg_lds = b2t_reg_lds_bytes<T, NT>();
-      hipLaunchKernelGGL((b2t_reg_kernel<T, NT>), dim3(g), dim3(NT), reg_lds, stream, a);
+      if (b == kB2tRegBand)
+        hipLaunchKernelGGL((b2t_reg_kernel<T, NT, true>), dim3(g), dim3(NT), reg_lds, stream, a);
+      else
+        hipLaunchKernelGGL((b2t_reg_kernel<T, NT, false>), dim3(g), dim3(NT), reg_lds, stream, a);
       return;
     }
   }

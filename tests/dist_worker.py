@@ -207,208 +207,211 @@ def main():
             ok &= bool(good)
             orig.close()
             fact.close()
-        # triangular solver: every side / uplo / op / diag on the reference's analytic systems
-        # (test/unit/solver/test_triangular.cpp:105-141), non-zero source ranks, both communication shapes
-        import itertools
-        for t, (m, n, nb) in [("d", (19, 25, 6)), ("z", (15, 7, 3)), ("d", (150, 70, 32)), ("s", (12, 13, 5)),
-                              ("d", (130, 200, 64))]:
-            dt = oracle.DTYPES[t]
-            alpha = dt(complex(-1.2, .7)) if t in "cz" else dt(-1.2)
-            for side, uplo, op, diag in itertools.product("LR", "LU", "NTC", "NU"):
-                a, b, x = oracle.triangular_system(side, uplo, op, diag, alpha, m, n, dt)
+        # the widenings (solver, gen_to_std, eigensolver stages): not repeated by the runs that only select another
+        # issue order of the Cholesky factorization (DIST_WORKER_CHOLESKY_ONLY=1)
+        if os.environ.get("DIST_WORKER_CHOLESKY_ONLY") != "1":
+            # triangular solver: every side / uplo / op / diag on the reference's analytic systems
+            # (test/unit/solver/test_triangular.cpp:105-141), non-zero source ranks, both communication shapes
+            import itertools
+            for t, (m, n, nb) in [("d", (19, 25, 6)), ("z", (15, 7, 3)), ("d", (150, 70, 32)), ("s", (12, 13, 5)),
+                                  ("d", (130, 200, 64))]:
+                dt = oracle.DTYPES[t]
+                alpha = dt(complex(-1.2, .7)) if t in "cz" else dt(-1.2)
+                for side, uplo, op, diag in itertools.product("LR", "LU", "NTC", "NU"):
+                    a, b, x = oracle.triangular_system(side, uplo, op, diag, alpha, m, n, dt)
+                    sr, sc = max(0, nprow - 1), min(1, npcol - 1)
+                    la = np.asfortranarray(oracle.scatter(a, nb, nprow, npcol, sr, sc, extra_ld=1)[(grid.myrow, grid.mycol)])
+                    lb = np.asfortranarray(oracle.scatter(b, nb, nprow, npcol, sr, sc, extra_ld=2)[(grid.myrow, grid.mycol)])
+                    dlaf.triangular_solver(grid, side, uplo, op, diag, alpha, la, lb, nb, m=m, n=n, a_src=(sr, sc),
+                                           b_src=(sr, sc))
+                    got = gather_global(lb, grid, n, nb, sr, sc, oracle, m=m)
+                    if rank == 0:
+                        tol = 20 * (m + 1) * (8 if t in "cz" else 2) * oracle.eps_of(dt)   # test_triangular.cpp:139-140
+                        good, md = oracle.check_near(x, got, tol, tol)
+                        if not good:
+                            print(f"[dist_worker] solver FAILED {t} {side}{uplo}{op}{diag} {m}x{n} nb={nb} "
+                                  f"grid {nprow}x{npcol}: max diff {md} tol {tol}", flush=True)
+                        ok &= bool(good)
+            # generalized_to_standard on the grid: the reference's distributed test (test_gen_to_std.cpp:85-113) --
+            # analytic operands, non-zero source rank, abs tolerance 10 (m+1) error, the factor untouched -- plus
+            # random operands against the oracle's restatement of GenToStd::call_L
+            for t, uplo, m, mb in [("d", "L", 34, 13), ("d", "U", 34, 13), ("z", "L", 32, 5), ("z", "U", 16, 10), ("s", "L", 34, 34),
+                                   ("c", "U", 5, 8), ("d", "L", 4, 3), ("d", "L", 0, 2), ("d", "U", 200, 32), ("z", "L", 150, 32)]:
+                dt = oracle.DTYPES[t]
                 sr, sc = max(0, nprow - 1), min(1, npcol - 1)
-                la = np.asfortranarray(oracle.scatter(a, nb, nprow, npcol, sr, sc, extra_ld=1)[(grid.myrow, grid.mycol)])
-                lb = np.asfortranarray(oracle.scatter(b, nb, nprow, npcol, sr, sc, extra_ld=2)[(grid.myrow, grid.mycol)])
-                dlaf.triangular_solver(grid, side, uplo, op, diag, alpha, la, lb, nb, m=m, n=n, a_src=(sr, sc),
-                                       b_src=(sr, sc))
-                got = gather_global(lb, grid, n, nb, sr, sc, oracle, m=m)
+                tmat, a, b = oracle.gen_to_std_setters(uplo, m, dt)
+                la = np.asfortranarray(oracle.scatter(a, mb, nprow, npcol, sr, sc, extra_ld=1)[(grid.myrow, grid.mycol)])
+                lt = np.asfortranarray(oracle.scatter(tmat, mb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
+                lt0 = lt.copy(order="F")
+                ok &= dlaf.generalized_to_standard(grid, uplo, la, lt, mb, sr, sc, n=m) == 0
+                got = gather_global(la, grid, m, mb, sr, sc, oracle)
+                ok &= bool(np.array_equal(lt, lt0))
                 if rank == 0:
-                    tol = 20 * (m + 1) * (8 if t in "cz" else 2) * oracle.eps_of(dt)   # test_triangular.cpp:139-140
-                    good, md = oracle.check_near(x, got, tol, tol)
+                    err = (8 if t in "cz" else 2) * oracle.eps_of(dt)
+                    good, md = oracle.check_near(b, got, 0, 10 * (m + 1) * err)
                     if not good:
-                        print(f"[dist_worker] solver FAILED {t} {side}{uplo}{op}{diag} {m}x{n} nb={nb} "
-                              f"grid {nprow}x{npcol}: max diff {md} tol {tol}", flush=True)
+                        print(f"[dist_worker] gen_to_std FAILED {t}{uplo} m={m} mb={mb} grid {nprow}x{npcol}: max diff {md}", flush=True)
                     ok &= bool(good)
-        # generalized_to_standard on the grid: the reference's distributed test (test_gen_to_std.cpp:85-113) --
-        # analytic operands, non-zero source rank, abs tolerance 10 (m+1) error, the factor untouched -- plus
-        # random operands against the oracle's restatement of GenToStd::call_L
-        for t, uplo, m, mb in [("d", "L", 34, 13), ("d", "U", 34, 13), ("z", "L", 32, 5), ("z", "U", 16, 10), ("s", "L", 34, 34),
-                               ("c", "U", 5, 8), ("d", "L", 4, 3), ("d", "L", 0, 2), ("d", "U", 200, 32), ("z", "L", 150, 32)]:
-            dt = oracle.DTYPES[t]
-            sr, sc = max(0, nprow - 1), min(1, npcol - 1)
-            tmat, a, b = oracle.gen_to_std_setters(uplo, m, dt)
-            la = np.asfortranarray(oracle.scatter(a, mb, nprow, npcol, sr, sc, extra_ld=1)[(grid.myrow, grid.mycol)])
-            lt = np.asfortranarray(oracle.scatter(tmat, mb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
-            lt0 = lt.copy(order="F")
-            ok &= dlaf.generalized_to_standard(grid, uplo, la, lt, mb, sr, sc, n=m) == 0
-            got = gather_global(la, grid, m, mb, sr, sc, oracle)
-            ok &= bool(np.array_equal(lt, lt0))
-            if rank == 0:
-                err = (8 if t in "cz" else 2) * oracle.eps_of(dt)
-                good, md = oracle.check_near(b, got, 0, 10 * (m + 1) * err)
-                if not good:
-                    print(f"[dist_worker] gen_to_std FAILED {t}{uplo} m={m} mb={mb} grid {nprow}x{npcol}: max diff {md}", flush=True)
+            for t, uplo, n, nb in [("d", "L", 530, 64), ("z", "U", 300, 32)]:
+                dt = oracle.DTYPES[t]
+                sr, sc = 0, 0
+                b0 = oracle.set_random_hpd(n, nb, dt)
+                a0 = (oracle.set_random_hpd(n, nb, dt) * dt(1.0 / n)).astype(dt)
+                fac = b0.copy(order="F")
+                assert oracle.cholesky_local(uplo, fac, nb) == 0
+                la = np.asfortranarray(oracle.scatter(a0, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
+                lf = np.asfortranarray(oracle.scatter(fac, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
+                ok &= dlaf.generalized_to_standard(grid, uplo, la, lf, nb, sr, sc, n=n) == 0
+                got = gather_global(la, grid, n, nb, sr, sc, oracle)
+                if rank == 0:
+                    ref = a0.copy(order="F")
+                    oracle.gen_to_std_local(uplo, ref, fac, nb)
+                    err = (8 if t in "cz" else 2) * oracle.eps_of(dt)
+                    tol = 10 * (n + 1) * err * max(1.0, np.abs(oracle.tri(uplo, ref)).max())
+                    good, md = oracle.check_near(oracle.tri(uplo, ref), oracle.tri(uplo, got), 0, tol)
+                    other = np.triu(got, 1) if uplo == "L" else np.tril(got, -1)
+                    good &= bool(np.array_equal(other, np.triu(a0, 1) if uplo == "L" else np.tril(a0, -1)))
+                    if not good:
+                        print(f"[dist_worker] gen_to_std random FAILED {t}{uplo} n={n} nb={nb}: max diff {md} tol {tol}", flush=True)
+                    ok &= bool(good)
+            # reduction_to_band + bt_reduction_to_band on the grid: the reference's distributed test
+            # (test_reduction_to_band.cpp:405-489 -- its size lists on the 6-rank grids, checkResult: Q B Q^H == A within
+            # n^2 * error, the upper triangle untouched) plus fast-path sizes, a non-zero source rank, elementwise against
+            # the oracle's restatement of ReductionToBand::call; then C <- Q C against the oracle (test_bt_reduction_to_band.cpp)
+            from oracle import red2band as rb
+            for t, n, nb, band, src in [("d", 13, 3, 3, 0), ("d", 24, 3, 3, 1), ("d", 40, 5, 5, 0), ("z", 42, 6, 3, 1), ("d", 29, 9, 3, 0),
+                                        ("s", 42, 12, 4, 0), ("c", 27, 9, 3, 1), ("d", 4, 4, 2, 0), ("d", 300, 64, 32, 1),
+                                        ("z", 260, 64, 32, 0), ("d", 515, 128, 64, 1), ("d", 0, 6, 2, 0)]:
+                dt = oracle.DTYPES[t]
+                sr, sc = (max(0, nprow - 1), min(1, npcol - 1)) if src else (0, 0)
+                a0 = rb.random_hermitian(n, dt, seed=300 + n)
+                poisoned = a0.copy(order="F")
+                poisoned[np.triu_indices(n, 1)] = -9.9
+                la = np.asfortranarray(oracle.scatter(poisoned, nb, nprow, npcol, sr, sc, extra_ld=1)[(grid.myrow, grid.mycol)])
+                taus = dlaf.reduction_to_band(grid, la, nb, band, sr, sc, n=n)
+                got = gather_global(la, grid, n, nb, sr, sc, oracle)
+                all_taus = [None] * dist.get_world_size()
+                dist.all_gather_object(all_taus, taus)
+                good = all(np.array_equal(all_taus[0], x) for x in all_taus)   # replicated, bit for bit
+                if rank == 0 and n:
+                    good &= bool((got[np.triu_indices(n, 1)] == dt(-9.9)).all())
+                    okc, diff, tol = rb.check_result(a0, got, taus, band)
+                    ref = a0.copy(order="F")
+                    rtaus = rb.reduction_to_band(ref, nb, band)
+                    dm = np.abs(np.tril(ref) - np.tril(got)).max()
+                    good &= bool(okc) and dm <= tol and (len(taus) == 0 or np.abs(rtaus - taus).max() <= tol)
+                    if not good:
+                        print(f"[dist_worker] reduction_to_band FAILED {t} n={n} nb={nb} band={band} src=({sr},{sc}) grid "
+                              f"{nprow}x{npcol}: checkResult diff {diff} tol {tol}, vs oracle {dm}", flush=True)
                 ok &= bool(good)
-        for t, uplo, n, nb in [("d", "L", 530, 64), ("z", "U", 300, 32)]:
-            dt = oracle.DTYPES[t]
-            sr, sc = 0, 0
-            b0 = oracle.set_random_hpd(n, nb, dt)
-            a0 = (oracle.set_random_hpd(n, nb, dt) * dt(1.0 / n)).astype(dt)
-            fac = b0.copy(order="F")
-            assert oracle.cholesky_local(uplo, fac, nb) == 0
-            la = np.asfortranarray(oracle.scatter(a0, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
-            lf = np.asfortranarray(oracle.scatter(fac, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
-            ok &= dlaf.generalized_to_standard(grid, uplo, la, lf, nb, sr, sc, n=n) == 0
-            got = gather_global(la, grid, n, nb, sr, sc, oracle)
-            if rank == 0:
-                ref = a0.copy(order="F")
-                oracle.gen_to_std_local(uplo, ref, fac, nb)
-                err = (8 if t in "cz" else 2) * oracle.eps_of(dt)
-                tol = 10 * (n + 1) * err * max(1.0, np.abs(oracle.tri(uplo, ref)).max())
-                good, md = oracle.check_near(oracle.tri(uplo, ref), oracle.tri(uplo, got), 0, tol)
-                other = np.triu(got, 1) if uplo == "L" else np.tril(got, -1)
-                good &= bool(np.array_equal(other, np.triu(a0, 1) if uplo == "L" else np.tril(a0, -1)))
-                if not good:
-                    print(f"[dist_worker] gen_to_std random FAILED {t}{uplo} n={n} nb={nb}: max diff {md} tol {tol}", flush=True)
+                # back-transformation with these reflectors
+                k = max(1, (2 * n) // 3 + 1)
+                rng = np.random.default_rng(11)
+                c0 = rng.uniform(-1, 1, (n, k)) + (1j * rng.uniform(-1, 1, (n, k)) if t in "cz" else 0)
+                c0 = np.asfortranarray(c0.astype(dt))
+                csc = min(npcol - 1, 1) if src else 0
+                lc = np.asfortranarray(oracle.scatter(c0, nb, nprow, npcol, sr, csc, extra_ld=2)[(grid.myrow, grid.mycol)])
+                dlaf.bt_reduction_to_band(grid, band, lc, la, taus, nb, sr, sc, csc, n=n, k=k)
+                gotc = gather_global(lc, grid, k, nb, sr, csc, oracle, m=n)
+                if rank == 0 and n:
+                    refc = c0.copy(order="F")
+                    rb.bt_reduction_to_band(refc, got, taus, nb, band)
+                    tolc = max(1, n) * max(1, k) * rb.error_of(dt)
+                    goodc = bool(np.abs(gotc - refc).max() <= tolc)
+                    if not goodc:
+                        print(f"[dist_worker] bt_reduction_to_band FAILED {t} n={n} nb={nb} band={band} k={k} grid {nprow}x{npcol}: "
+                              f"max diff {np.abs(gotc - refc).max()} tol {tolc}", flush=True)
+                    ok &= goodc
+            # band_to_tridiagonal on the grid (test_band_to_tridiag.cpp:151-183: the reference's reconstruction check, a
+            # non-zero source rank): every rank ends up with the whole tridiagonal matrix and reflectors, bit-identical
+            from oracle import tridiag as td
+            for t, n, nb, band, src in [("d", 18, 4, 4, 1), ("z", 34, 6, 6, 0), ("d", 37, 9, 3, 1), ("c", 16, 12, 6, 0),
+                                        ("d", 300, 32, 16, 1), ("z", 260, 64, 32, 1)]:
+                dt = oracle.DTYPES[t]
+                sr, sc = (max(0, nprow - 1), min(1, npcol - 1)) if src else (0, 0)
+                a0 = rb.random_hermitian(n, dt, seed=500 + n, banded=band)
+                la = np.asfortranarray(oracle.scatter(a0, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
+                d_, e_, v_ = dlaf.band_to_tridiagonal(grid, la, nb, band, sr, sc, n=n)
+                allr = [None] * dist.get_world_size()
+                dist.all_gather_object(allr, (d_, e_, v_))
+                good = all(np.array_equal(allr[0][0], x[0]) and np.array_equal(allr[0][1], x[1]) and
+                           np.array_equal(allr[0][2], x[2]) for x in allr)
+                if rank == 0:
+                    okc, diff, bar = td.check_band_to_tridiag(a0, band, d_, e_, v_)
+                    good &= bool(okc)
+                    if not good:
+                        print(f"[dist_worker] band_to_tridiagonal FAILED {t} n={n} nb={nb} band={band} grid {nprow}x{npcol}: {diff} {bar}",
+                              flush=True)
                 ok &= bool(good)
-        # reduction_to_band + bt_reduction_to_band on the grid: the reference's distributed test
-        # (test_reduction_to_band.cpp:405-489 -- its size lists on the 6-rank grids, checkResult: Q B Q^H == A within
-        # n^2 * error, the upper triangle untouched) plus fast-path sizes, a non-zero source rank, elementwise against
-        # the oracle's restatement of ReductionToBand::call; then C <- Q C against the oracle (test_bt_reduction_to_band.cpp)
-        from oracle import red2band as rb
-        for t, n, nb, band, src in [("d", 13, 3, 3, 0), ("d", 24, 3, 3, 1), ("d", 40, 5, 5, 0), ("z", 42, 6, 3, 1), ("d", 29, 9, 3, 0),
-                                    ("s", 42, 12, 4, 0), ("c", 27, 9, 3, 1), ("d", 4, 4, 2, 0), ("d", 300, 64, 32, 1),
-                                    ("z", 260, 64, 32, 0), ("d", 515, 128, 64, 1), ("d", 0, 6, 2, 0)]:
-            dt = oracle.DTYPES[t]
-            sr, sc = (max(0, nprow - 1), min(1, npcol - 1)) if src else (0, 0)
-            a0 = rb.random_hermitian(n, dt, seed=300 + n)
-            poisoned = a0.copy(order="F")
-            poisoned[np.triu_indices(n, 1)] = -9.9
-            la = np.asfortranarray(oracle.scatter(poisoned, nb, nprow, npcol, sr, sc, extra_ld=1)[(grid.myrow, grid.mycol)])
-            taus = dlaf.reduction_to_band(grid, la, nb, band, sr, sc, n=n)
-            got = gather_global(la, grid, n, nb, sr, sc, oracle)
-            all_taus = [None] * dist.get_world_size()
-            dist.all_gather_object(all_taus, taus)
-            good = all(np.array_equal(all_taus[0], x) for x in all_taus)   # replicated, bit for bit
-            if rank == 0 and n:
-                good &= bool((got[np.triu_indices(n, 1)] == dt(-9.9)).all())
-                okc, diff, tol = rb.check_result(a0, got, taus, band)
-                ref = a0.copy(order="F")
-                rtaus = rb.reduction_to_band(ref, nb, band)
-                dm = np.abs(np.tril(ref) - np.tril(got)).max()
-                good &= bool(okc) and dm <= tol and (len(taus) == 0 or np.abs(rtaus - taus).max() <= tol)
-                if not good:
-                    print(f"[dist_worker] reduction_to_band FAILED {t} n={n} nb={nb} band={band} src=({sr},{sc}) grid "
-                          f"{nprow}x{npcol}: checkResult diff {diff} tol {tol}, vs oracle {dm}", flush=True)
-            ok &= bool(good)
-            # back-transformation with these reflectors
-            k = max(1, (2 * n) // 3 + 1)
-            rng = np.random.default_rng(11)
-            c0 = rng.uniform(-1, 1, (n, k)) + (1j * rng.uniform(-1, 1, (n, k)) if t in "cz" else 0)
-            c0 = np.asfortranarray(c0.astype(dt))
-            csc = min(npcol - 1, 1) if src else 0
-            lc = np.asfortranarray(oracle.scatter(c0, nb, nprow, npcol, sr, csc, extra_ld=2)[(grid.myrow, grid.mycol)])
-            dlaf.bt_reduction_to_band(grid, band, lc, la, taus, nb, sr, sc, csc, n=n, k=k)
-            gotc = gather_global(lc, grid, k, nb, sr, csc, oracle, m=n)
-            if rank == 0 and n:
-                refc = c0.copy(order="F")
-                rb.bt_reduction_to_band(refc, got, taus, nb, band)
-                tolc = max(1, n) * max(1, k) * rb.error_of(dt)
-                goodc = bool(np.abs(gotc - refc).max() <= tolc)
-                if not goodc:
-                    print(f"[dist_worker] bt_reduction_to_band FAILED {t} n={n} nb={nb} band={band} k={k} grid {nprow}x{npcol}: "
-                          f"max diff {np.abs(gotc - refc).max()} tol {tolc}", flush=True)
-                ok &= goodc
-        # band_to_tridiagonal on the grid (test_band_to_tridiag.cpp:151-183: the reference's reconstruction check, a
-        # non-zero source rank): every rank ends up with the whole tridiagonal matrix and reflectors, bit-identical
-        from oracle import tridiag as td
-        for t, n, nb, band, src in [("d", 18, 4, 4, 1), ("z", 34, 6, 6, 0), ("d", 37, 9, 3, 1), ("c", 16, 12, 6, 0),
-                                    ("d", 300, 32, 16, 1), ("z", 260, 64, 32, 1)]:
-            dt = oracle.DTYPES[t]
-            sr, sc = (max(0, nprow - 1), min(1, npcol - 1)) if src else (0, 0)
-            a0 = rb.random_hermitian(n, dt, seed=500 + n, banded=band)
-            la = np.asfortranarray(oracle.scatter(a0, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
-            d_, e_, v_ = dlaf.band_to_tridiagonal(grid, la, nb, band, sr, sc, n=n)
-            allr = [None] * dist.get_world_size()
-            dist.all_gather_object(allr, (d_, e_, v_))
-            good = all(np.array_equal(allr[0][0], x[0]) and np.array_equal(allr[0][1], x[1]) and
-                       np.array_equal(allr[0][2], x[2]) for x in allr)
-            if rank == 0:
-                okc, diff, bar = td.check_band_to_tridiag(a0, band, d_, e_, v_)
-                good &= bool(okc)
-                if not good:
-                    print(f"[dist_worker] band_to_tridiagonal FAILED {t} n={n} nb={nb} band={band} grid {nprow}x{npcol}: {diff} {bar}",
-                          flush=True)
-            ok &= bool(good)
-        # hermitian_eigensolver / hermitian_generalized_eigensolver on the grid through the reference's C entries
-        # (test_eigensolver.cpp, test_gen_eigensolver.cpp: testEigensolverCorrectness on the gathered results; A and the
-        # eigenvector matrix with different source columns)
-        for t, n, nb, src in [("d", 34, 8, 1), ("z", 64, 16, 0), ("s", 32, 5, 1), ("d", 300, 32, 1), ("z", 260, 64, 0),
-                              ("d", 1100, 256, 1), ("d", 5, 8, 0)]:
-            dt = oracle.DTYPES[t]
-            sr, sc = (max(0, nprow - 1), min(1, npcol - 1)) if src else (0, 0)
-            zsc = 0 if src else min(1, npcol - 1)
-            a0 = rb.random_hermitian(n, dt, seed=700 + n)
-            la = np.asfortranarray(oracle.scatter(a0, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
-            zshape = grid.local_shape(n, nb, sr, zsc)
-            w, lz = dlaf.hermitian_eigensolver(grid, "L", la, nb, sr, sc, n=n, z_jsrc=zsc, z_shape=zshape)
-            z = gather_global(lz, grid, n, nb, sr, zsc, oracle)
-            allw = [None] * dist.get_world_size()
-            dist.all_gather_object(allw, w)
-            good = all(np.array_equal(allw[0], x) for x in allw)
-            if rank == 0:
-                res = td.check_eigensolver(a0, w, z)
-                good &= res["sorted"] and res["orth"] <= res["orth_bar"] and res["residual_ok"]
-                if not good:
-                    print(f"[dist_worker] hermitian_eigensolver FAILED {t} n={n} nb={nb} grid {nprow}x{npcol}: {res}", flush=True)
-            ok &= bool(good)
-        for t, n, nb in [("d", 64, 16), ("z", 130, 32)]:
-            dt = oracle.DTYPES[t]
-            sr, sc = max(0, nprow - 1), min(1, npcol - 1)
-            a0 = rb.random_hermitian(n, dt, seed=900 + n)
-            b0 = rb.random_hermitian(n, dt, seed=901 + n)
-            b0 = np.asfortranarray((b0 @ b0.conj().T / n + 2 * np.eye(n)).astype(dt))
-            la = np.asfortranarray(oracle.scatter(a0, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
-            lb = np.asfortranarray(oracle.scatter(b0, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
-            w, lz = dlaf.hermitian_generalized_eigensolver(grid, "L", la, lb, nb, sr, sc, n=n)
-            z = gather_global(lz, grid, n, nb, sr, sc, oracle)
-            if rank == 0:
-                err = td.error_of(dt)
-                g_ = z.conj().T @ b0 @ z
-                r_ = a0 @ z - (b0 @ z) * w[None, :]
-                good = bool(np.all(np.diff(w) >= 0)) and np.abs(g_ - np.eye(n)).max() <= 10 * n * err * np.abs(b0).max() and \
-                    np.abs(r_).max() <= 10 * n * err * max(1.0, np.abs(a0).max() * np.abs(w).max())
-                if not good:
-                    print(f"[dist_worker] generalized eigensolver FAILED {t} n={n} nb={nb} grid {nprow}x{npcol}: "
-                          f"{np.abs(g_ - np.eye(n)).max()} {np.abs(r_).max()}", flush=True)
+            # hermitian_eigensolver / hermitian_generalized_eigensolver on the grid through the reference's C entries
+            # (test_eigensolver.cpp, test_gen_eigensolver.cpp: testEigensolverCorrectness on the gathered results; A and the
+            # eigenvector matrix with different source columns)
+            for t, n, nb, src in [("d", 34, 8, 1), ("z", 64, 16, 0), ("s", 32, 5, 1), ("d", 300, 32, 1), ("z", 260, 64, 0),
+                                  ("d", 1100, 256, 1), ("d", 5, 8, 0)]:
+                dt = oracle.DTYPES[t]
+                sr, sc = (max(0, nprow - 1), min(1, npcol - 1)) if src else (0, 0)
+                zsc = 0 if src else min(1, npcol - 1)
+                a0 = rb.random_hermitian(n, dt, seed=700 + n)
+                la = np.asfortranarray(oracle.scatter(a0, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
+                zshape = grid.local_shape(n, nb, sr, zsc)
+                w, lz = dlaf.hermitian_eigensolver(grid, "L", la, nb, sr, sc, n=n, z_jsrc=zsc, z_shape=zshape)
+                z = gather_global(lz, grid, n, nb, sr, zsc, oracle)
+                allw = [None] * dist.get_world_size()
+                dist.all_gather_object(allw, w)
+                good = all(np.array_equal(allw[0], x) for x in allw)
+                if rank == 0:
+                    res = td.check_eigensolver(a0, w, z)
+                    good &= res["sorted"] and res["orth"] <= res["orth_bar"] and res["residual_ok"]
+                    if not good:
+                        print(f"[dist_worker] hermitian_eigensolver FAILED {t} n={n} nb={nb} grid {nprow}x{npcol}: {res}", flush=True)
                 ok &= bool(good)
-        # p?potrf -> p?potrs on resident matrices over the grid (no host staging between the factorization and the
-        # two solves), and one resident solve per side against the oracle
-        for t, uplo, n, nrhs, nb in [("d", "L", 300, 90, 32), ("z", "U", 200, 70, 32)]:
-            dt = oracle.DTYPES[t]
-            a0 = oracle.set_random_hpd(n, nb, dt)
-            rng = np.random.default_rng(5)
-            xs = rng.uniform(-1, 1, (n, nrhs)) + (1j * rng.uniform(-1, 1, (n, nrhs)) if t == "z" else 0)
-            xs = np.asfortranarray(xs.astype(dt))
-            rhs = np.asfortranarray(a0 @ xs)
-            sr, sc = max(0, nprow - 1), min(1, npcol - 1)
-            la = np.asfortranarray(oracle.scatter(a0, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
-            lb = np.asfortranarray(oracle.scatter(rhs, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
-            am = dlaf.DeviceMatrix(grid, dt, uplo, n, nb, sr, sc)
-            am.upload(la)
-            bm = dlaf.GeneralDeviceMatrix(grid, dt, n, nrhs, nb, sr, sc)
-            bm.upload(lb)
-            ok &= am.factorize() == 0
-            dlaf.potrs_device(uplo, am, bm)
-            bm.download(lb)
-            got = gather_global(lb, grid, nrhs, nb, sr, sc, oracle, m=n)
-            if rank == 0:
-                good = bool(np.abs(got - xs).max() <= 100 * n * oracle.eps_of(dt))
-                if not good:
-                    print(f"[dist_worker] resident potrs FAILED {t}{uplo}: max diff {np.abs(got - xs).max()}", flush=True)
-                ok &= good
-            am.close()
-            bm.close()
+            for t, n, nb in [("d", 64, 16), ("z", 130, 32)]:
+                dt = oracle.DTYPES[t]
+                sr, sc = max(0, nprow - 1), min(1, npcol - 1)
+                a0 = rb.random_hermitian(n, dt, seed=900 + n)
+                b0 = rb.random_hermitian(n, dt, seed=901 + n)
+                b0 = np.asfortranarray((b0 @ b0.conj().T / n + 2 * np.eye(n)).astype(dt))
+                la = np.asfortranarray(oracle.scatter(a0, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
+                lb = np.asfortranarray(oracle.scatter(b0, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
+                w, lz = dlaf.hermitian_generalized_eigensolver(grid, "L", la, lb, nb, sr, sc, n=n)
+                z = gather_global(lz, grid, n, nb, sr, sc, oracle)
+                if rank == 0:
+                    err = td.error_of(dt)
+                    g_ = z.conj().T @ b0 @ z
+                    r_ = a0 @ z - (b0 @ z) * w[None, :]
+                    good = bool(np.all(np.diff(w) >= 0)) and np.abs(g_ - np.eye(n)).max() <= 10 * n * err * np.abs(b0).max() and \
+                        np.abs(r_).max() <= 10 * n * err * max(1.0, np.abs(a0).max() * np.abs(w).max())
+                    if not good:
+                        print(f"[dist_worker] generalized eigensolver FAILED {t} n={n} nb={nb} grid {nprow}x{npcol}: "
+                              f"{np.abs(g_ - np.eye(n)).max()} {np.abs(r_).max()}", flush=True)
+                    ok &= bool(good)
+            # p?potrf -> p?potrs on resident matrices over the grid (no host staging between the factorization and the
+            # two solves), and one resident solve per side against the oracle
+            for t, uplo, n, nrhs, nb in [("d", "L", 300, 90, 32), ("z", "U", 200, 70, 32)]:
+                dt = oracle.DTYPES[t]
+                a0 = oracle.set_random_hpd(n, nb, dt)
+                rng = np.random.default_rng(5)
+                xs = rng.uniform(-1, 1, (n, nrhs)) + (1j * rng.uniform(-1, 1, (n, nrhs)) if t == "z" else 0)
+                xs = np.asfortranarray(xs.astype(dt))
+                rhs = np.asfortranarray(a0 @ xs)
+                sr, sc = max(0, nprow - 1), min(1, npcol - 1)
+                la = np.asfortranarray(oracle.scatter(a0, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
+                lb = np.asfortranarray(oracle.scatter(rhs, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
+                am = dlaf.DeviceMatrix(grid, dt, uplo, n, nb, sr, sc)
+                am.upload(la)
+                bm = dlaf.GeneralDeviceMatrix(grid, dt, n, nrhs, nb, sr, sc)
+                bm.upload(lb)
+                ok &= am.factorize() == 0
+                dlaf.potrs_device(uplo, am, bm)
+                bm.download(lb)
+                got = gather_global(lb, grid, nrhs, nb, sr, sc, oracle, m=n)
+                if rank == 0:
+                    good = bool(np.abs(got - xs).max() <= 100 * n * oracle.eps_of(dt))
+                    if not good:
+                        print(f"[dist_worker] resident potrs FAILED {t}{uplo}: max diff {np.abs(got - xs).max()}", flush=True)
+                    ok &= good
+                am.close()
+                bm.close()
         # analytic known-answer matrix through the ScaLAPACK-style entry (test_cholesky_c_api.cpp:108-155)
         n, nb = 34, 13
         a, l = oracle.cholesky_setters("L", n, np.float64)

@@ -81,7 +81,8 @@ def test_distributed_cholesky_one_gpu_many_ranks(nprow, npcol, order):
 @pytest.mark.parametrize("nprow,npcol,order", [(2, 2, "R"), (1, 3, "R")])
 def test_distributed_cholesky_classic_schedule(nprow, npcol, order):
     """Process grids default to the early-diagonal issue order; the classic one stays selectable."""
-    launch("gpu", nprow, npcol, order, timeout=600, extra_env={"DLAF_MI355X_SCHEDULE": "classic"})
+    launch("gpu", nprow, npcol, order, timeout=600, extra_env={"DLAF_MI355X_SCHEDULE": "classic",
+                                                               "DIST_WORKER_CHOLESKY_ONLY": "1"})
 
 
 RCCL_SINGLE = r"""
