@@ -583,9 +583,8 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char b2t_raw[];
   const int b = p.b, ldb = 2 * b;
   T* Lv = reinterpret_cast<T*>(b2t_raw);  // [v ; 0]: the reflector over the rows of the block
-  T* Lw = Lv + kB2tExt;                   // [w ; tau B v]
-  T* Lwd = Lw + kB2tExt;                  // [w ; 0]
-  T* Lv2 = Lwd + kB2tExt;                 // [0 ; v2]: the new reflector at the rows of B
+  T* Lwd = Lv + kB2tExt;                  // NW x [w ; 0]: every wave's own copy of w over the diagonal block
+  T* Lv2 = Lwd + (size_t) NW * kB2tExt;   // [0 ; first column of B]: the next reflector's input
   T* Lcs = Lv2 + kB2tExt;                 // per column: (strictly lower D)^H v
   T* Lzw = Lcs + kB2tRegBand;             // NW x kB2tExt partial products A v
   T* Lsc = Lzw + (size_t) NW * kB2tExt;   // [0] tau, [1] tau2, [2] alpha, [3] beta
@@ -741,51 +740,45 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
       for (int q = 0; q < QN; ++q)
         Lzw[(size_t) wave * kB2tExt + ln + 64 * q] = zacc[q];
       __syncthreads();
-      // ---- P2: wx = [tau (z + cs) - 1/2 tau (w^H v) v ; tau B v ; 0] ----------------------------------------------------
-      for (int r = tid; r < kB2tExt; r += NT) {
-        T sum = zero_el<T>();
-#pragma unroll
-        for (int q = 0; q < NW; ++q)
-          sum = c_add(sum, Lzw[(size_t) q * kB2tExt + r]);
-        T w = zero_el<T>();
-        if (r < nh)
-          w = c_mul(tau, c_add(sum, Lcs[r]));
-        else if (r < rows)
-          w = c_mul(tau, sum);
-        Lw[r] = w;
-        Lv2[r] = zero_el<T>();
-        Lwd[r] = zero_el<T>();
-      }
-      __syncthreads();
-      if (wave == 0) {
-        T dot = zero_el<T>();
-        for (int r = lane; r < nh; r += 64)
-          dot = c_add(dot, c_cmul(Lw[r], Lv[r]));
-        dot = wave_sum_t(dot);
-        if (lane == 0)
-          Lsc[2] = c_scale(c_mul(dot, tau), R(-0.5));
-      }
-      __syncthreads();
+      // ---- P2 (every wave for itself: no workgroup barrier): wx = [tau (z + cs) - 1/2 tau (w^H v) v ; tau B v ; 0] over
+      //      the wave's own four rows per lane; w over the diagonal block also goes to the wave's LDS copy, from which the
+      //      column operands conj(w_c) are broadcast
+      T wr[QN];
       {
-        const T alpha = Lsc[2];
-        for (int r = tid; r < nh; r += NT) {
-          const T w = c_add(Lw[r], c_mul(alpha, Lv[r]));
-          Lw[r] = w;
-          Lwd[r] = w;
+        T dotp = zero_el<T>();
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+          const int r = ln + 64 * q;
+          T sum = zero_el<T>();
+#pragma unroll
+          for (int u = 0; u < NW; ++u)
+            sum = c_add(sum, Lzw[(size_t) u * kB2tExt + r]);
+          T w = zero_el<T>();
+          if (r < nh)
+            w = c_mul(tau, c_add(sum, Lcs[r]));
+          else if (r < rows)
+            w = c_mul(tau, sum);
+          wr[q] = w;
+          dotp = c_add(dotp, c_cmul(w, vr[q]));  // (vr is zero beyond the diagonal block)
         }
-      }
-      __syncthreads();
-      // ---- P3: A -= wx conj(v_c) + vx conj(w_c)  (two-sided update of D, right update of B) -----------------------------
-      {
-        T wr[QN];
+        const T dot = wave_sum_t(dotp);
+        const T alpha = c_scale(c_mul(dot, tau), R(-0.5));
+        T* wd = Lwd + (size_t) wave * kB2tExt;
 #pragma unroll
-        for (int q = 0; q < QN; ++q)
-          wr[q] = Lw[ln + 64 * q];
+        for (int q = 0; q < QN; ++q) {
+          const int r = ln + 64 * q;
+          wr[q] = c_add(wr[q], c_mul(alpha, vr[q]));
+          wd[r] = r < nh ? wr[q] : zero_el<T>();
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- P3: A -= wx conj(v_c) + vx conj(w_c)  (two-sided update of D, right update of B) ---------------------------
 #pragma unroll
         for (int k = 0; k < CPW; ++k) {
           const int cc = wave + NW * k;
           const T vcc = c_conj(Lv[cc]);
-          const T wcc = c_conj(Lwd[cc]);
+          const T wcc = c_conj(wd[cc]);
 #pragma unroll
           for (int q = 0; q < QN; ++q) {
             const int r = ln + 64 * q;
@@ -804,27 +797,44 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
         }
       }
       __syncthreads();
-      // ---- P4: the reflector of the first column of B (in place in v2x) ------------------------------------------------
-      if (wave == 0) {
-        T tau2 = zero_el<T>(), beta = m > 0 ? Lv2[nh] : zero_el<T>();
-        if (m > 1)
-          wave_larfg(Lv2 + nh, m, lane, tau2, beta);
-        else if (m == 1 && lane == 0)
-          Lv2[nh] = zero_el<T>();  // (no reflector: the element stays as it is)
-        if (lane == 0) {
-          Lsc[1] = tau2;
-          Lsc[3] = beta;
+      // ---- P4 (every wave for itself): the reflector of the first column of B, xLARFG on the wave's registers ---------
+      T v2r[QN];
+      T tau2 = zero_el<T>(), beta = zero_el<T>();
+      {
+        R ss = R(0);
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+          const int r = ln + 64 * q;
+          v2r[q] = Lv2[r];
+          if (r > nh)
+            ss += c_abs2(v2r[q]);  // (zero outside the rows of B)
+        }
+        ss = wave_sum_t(ss);
+        const T alpha0 = Lv2[nh];  // (m == 0: row nh holds zero)
+        beta = alpha0;
+        const R ar = re_of(alpha0), ai = im_of(alpha0);
+        if (m > 1 && !(ss == R(0) && ai == R(0))) {
+          const R nrm = sqrt(ar * ar + ai * ai + ss);
+          const R bt = ar >= R(0) ? -nrm : nrm;
+          tau2 = make_el<T>((bt - ar) / bt, -ai / bt);
+          const R dr = ar - bt, di = ai;
+          const R dd = dr * dr + di * di;
+          const T scale = make_el<T>(dr / dd, -di / dd);
+#pragma unroll
+          for (int q = 0; q < QN; ++q)
+            v2r[q] = c_mul(v2r[q], scale);
+          beta = make_el<T>(bt, R(0));
+        }
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+          const int r = ln + 64 * q;
+          if (r == nh)
+            v2r[q] = m > 1 ? make_el<T>(R(1), R(0)) : zero_el<T>();  // (m <= 1: no reflector, nothing to apply)
         }
       }
-      __syncthreads();
       // ---- P5/6: A -= v2x (conj(tau2) conj(A_c^H v2)) on the columns of B but the first, then all stores ------------------
       {
-        const T ctau2 = c_conj(Lsc[1]);
-        const T beta = Lsc[3];
-        T v2r[QN];
-#pragma unroll
-        for (int q = 0; q < QN; ++q)
-          v2r[q] = Lv2[ln + 64 * q];
+        const T ctau2 = c_conj(tau2);
         asm volatile("" : "+v"(ln));
         const unsigned base_st = (unsigned) ((j * ldb + ln) * (long) sizeof(T));
         {
@@ -862,15 +872,22 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
           }
         }
       }
-      __syncthreads();
+      // the reflector of the next step (rows of B -> rows 0 .. m), written by wave 0; the barrier of publish() orders it
       if (m > 1) {
-        for (int r = tid; r < kB2tExt; r += NT)
-          Lv[r] = r < m ? Lv2[nh + r] : zero_el<T>();
-        if (tid == 0)
-          Lsc[0] = Lsc[1];
+        if (wave == 0) {
+#pragma unroll
+          for (int q = 0; q < QN; ++q) {
+            const int r = ln + 64 * q;
+            if (r >= nh && r < rows)
+              Lv[r - nh] = v2r[q];
+            if (r >= m && r < kB2tExt && (r < nh || r >= rows))
+              Lv[r] = zero_el<T>();
+          }
+          if (lane == 0)
+            Lsc[0] = tau2;
+        }
       }
       publish((unsigned) step + 1u);
-      __syncthreads();
     }
     if (!ok) {
       if (tid == 0) {
@@ -884,7 +901,7 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
 }
 template <class T, int NT>
 size_t b2t_reg_lds_bytes() {
-  return ((size_t) 4 * kB2tExt + kB2tRegBand + (size_t) (NT / 64) * kB2tExt + 8 + kB2tRegBand) * sizeof(T) + 16;
+  return ((size_t) 2 * kB2tExt + kB2tRegBand + (size_t) 2 * (NT / 64) * kB2tExt + 8 + kB2tRegBand) * sizeof(T) + 16;
 }
 
 // ======================================================================================= reflector blocks
