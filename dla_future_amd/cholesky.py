@@ -170,11 +170,14 @@ def pxpotrf(uplo: str, n: int, a: np.ndarray, ia: int, ja: int, desca) -> int:
 
 
 def triangular_solver(grid: Grid, side: str, uplo: str, op: str, diag: str, alpha, a: np.ndarray, b: np.ndarray,
-                      nb: int, m: int | None = None, n: int | None = None, a_src=(0, 0), b_src=(0, 0)) -> None:
+                      nb: int, m: int | None = None, n: int | None = None, a_src=(0, 0), b_src=(0, 0),
+                      b_block: tuple[int, int] | None = None) -> None:
     """dlaf::triangular_solver(grid, side, uplo, op, diag, alpha, A, B)
     (include/dlaf/solver/triangular.h:41-177) == dlaf_mi355x_triangular_solver_{s,d,c,z}:
     side 'L': op(A) X = alpha B, side 'R': X op(A) = alpha B; `b` (this process's local column-major part of
-    the m x n right-hand sides) is overwritten by X.  `a`: local part of the triangular matrix."""
+    the m x n right-hand sides) is overwritten by X.  `a`: local part of the triangular matrix.
+    `nb`: the square block of A; `b_block` = (MB, NB) of B when they differ (triangular.h:41-60: B's block along the
+    triangular dimension must be A's, the other one is free)."""
     t = type_char(b.dtype)
     if a.dtype != b.dtype:
         raise ValueError("A and B must have the same element type")
@@ -184,7 +187,8 @@ def triangular_solver(grid: Grid, side: str, uplo: str, op: str, diag: str, alph
         m, n = b.shape
     na = m if side.upper() == "L" else n
     da = DLAFDescriptor(na, na, nb, nb, a_src[0], a_src[1], 0, 0, _ld_of(a))
-    db = DLAFDescriptor(m, n, nb, nb, b_src[0], b_src[1], 0, 0, _ld_of(b))
+    mb_b, nb_b = b_block if b_block is not None else (nb, nb)
+    db = DLAFDescriptor(m, n, mb_b, nb_b, b_src[0], b_src[1], 0, 0, _ld_of(b))
     al = np.array([alpha], dtype=b.dtype)
     fn = getattr(lib(), f"dlaf_mi355x_triangular_solver_{t}")
     r = fn(grid.context, side.encode(), uplo.encode(), op.encode(), diag.encode(), _ptr(al), _ptr(a), da, _ptr(b), db)

@@ -63,10 +63,12 @@ struct UpdateArgs {
 // and triangular solver (same code, separate kernel names, so that profiles of the factorization stay clean)
 // max_blocks > 0 (with counters = 16 device words of scratch): launch at most that many workgroups and
 // let them pull work items (persistent form): what is left of the GPU stays free for kernels that
-// must run beside the update.
+// must run beside the update.  excl_slots > 0 (persistent form only): the workgroups that land on the first
+// compute units of every XCD -- as many whole compute units as hold excl_slots workgroups -- leave at once, so
+// max_blocks may cover the whole GPU and the side kernels still find compute units of their own.
 template <class T>
 void launch_update(const UpdateArgs<T>& args, hipStream_t stream, int role = 0, long max_blocks = 0,
-                   unsigned* counters = nullptr, bool counters_are_zero = false);
+                   unsigned* counters = nullptr, bool counters_are_zero = false, long excl_slots = 0);
 template <class T>
 int update_blocks_per_cu();
 

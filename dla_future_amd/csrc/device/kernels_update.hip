@@ -10,8 +10,13 @@
 //   * herk is the same code with a lower-triangle mask on diagonal tiles (and a real diagonal
 //     for complex types).
 // Roofline: MFMA-bound, 2*nb^3 flop per 4*nb^2*sizeof(T) algorithmic bytes per tile.
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
+#include <utility>
+#include <vector>
 
 #include "device_api.hpp"
 #include "mma_core.hpp"
@@ -79,7 +84,35 @@ struct UpdateMap {
                        // counters[8 + q]: work items of queue q that are finished (lockstep pacing)
   int lockstep;        // persist: the workgroups of a queue start their items in rounds (see update_kernel)
   unsigned kphase_ticks;  // persist: wall-clock ticks per K slab of a block (0: every block starts at slab 0)
+  int excl_rank;       // persist: workgroups that find themselves on one of the first `excl_rank` compute units of their
+                       // XCD (g_cu_rank) leave at once -- whole compute units stay free for the kernels beside the update
+  unsigned excl_budget;  // ... but no more than this many per launch (counters[15] counts them)
+  int steal;           // persist: a workgroup whose queue is empty drains the other queues
 };
+
+// Physical placement of the calling wave: XCD (HW_REG_XCC_ID[3:0]) and shader engine / array / compute unit
+// (HW_REG_HW_ID[15:8]).  Performance tool only: nothing depends on it for correctness.
+__device__ __forceinline__ unsigned phys_cu_key(unsigned& xcc) {
+  xcc = (unsigned) __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
+  return (unsigned) __builtin_amdgcn_s_getreg((7 << 11) | (8 << 6) | 4) & 0xffu;
+}
+
+// rank of a compute unit among the compute units of its XCD that the probe launch of update_kernels_init() saw
+// (255: not seen).  "The first r compute units of every XCD" is the set a persistent bulk launch vacates.
+__device__ unsigned char g_cu_rank[8][256];
+
+__global__ void cu_probe_kernel(unsigned* seen) {
+  extern __shared__ unsigned char probe_lds[];
+  if (threadIdx.x == 0) {
+    unsigned xcc;
+    const unsigned key = phys_cu_key(xcc);
+    atomicOr(&seen[xcc * 8 + (key >> 5)], 1u << (key & 31));
+    probe_lds[0] = (unsigned char) key;
+  }
+  // stay a little so that the launch spreads over every compute unit
+  for (int i = 0; i < 64; ++i)
+    __builtin_amdgcn_s_sleep(64);
+}
 
 // One work item = one BM x BN block of one tile.  Returns early for blocks outside the domain.
 // PART: 0 every block; 1 only the interior blocks (whole BM x BN, whole slabs, no triangle mask: the K loop on the
@@ -422,7 +455,7 @@ __global__ __launch_bounds__(UpdateCfg<T>::type::THREADS, UpdateCfg<T>::min_wave
   __shared__ unsigned next_item;
   const int nq = mp.xcd ? 8 : 1;
   const long per_q = mp.total / nq;
-  const int q = mp.xcd ? (int) (blockIdx.x & 7) : 0;
+  const int q0 = mp.xcd ? (int) (blockIdx.x & 7) : 0;
   // Lockstep pacing: the W workgroups of a queue (one XCD) take W consecutive work items -- neighbouring blocks
   // of one 8 x 8 patch, which stream the same 16 operand strips -- and start the next W only when those are done.
   // Blocks that start together stay within a few K slabs of each other, so a slab fetched by one of the 8 blocks
@@ -431,6 +464,24 @@ __global__ __launch_bounds__(UpdateCfg<T>::type::THREADS, UpdateCfg<T>::min_wave
   // 50 % (measured: TCC hit 48 %, 95 GB fetched per launch for 158 GB requested at N = 49152).  Pure pacing: no
   // data depends on it, the spin is bounded.
   const unsigned W = gridDim.x / nq;
+  // Exclusive compute units for the kernels that run beside this launch (tile POTRF strips, panel TRSM): the grid
+  // covers every workgroup slot of the GPU and the workgroups that land on a reserved compute unit leave, so the
+  // side kernels get whole compute units instead of sharing LDS / L1 / issue slots with a bulk workgroup.  The
+  // budget bounds the number that leave whatever the dispatcher does (e.g. slots of reserved compute units being
+  // handed out again and again while everything else is taken by another kernel).
+  if (mp.excl_rank > 0) {
+    __shared__ int leave;
+    if (threadIdx.x == 0) {
+      unsigned xcc;
+      const unsigned key = phys_cu_key(xcc);
+      leave = 0;
+      if ((int) g_cu_rank[xcc][key] < mp.excl_rank)
+        leave = atomicAdd(&mp.counters[15], 1u) < mp.excl_budget ? 1 : 0;
+    }
+    __syncthreads();
+    if (leave)
+      return;
+  }
   // K-phase alignment: the sum over k of a block may start anywhere, so every block starts at the slab "the wall
   // clock is at" -- (ticks / ticks-per-slab) mod slabs -- and wraps around.  Blocks of an XCD that stream the same
   // operand strips are then at (nearly) the same k whenever they started, instead of wherever their start time
@@ -443,6 +494,7 @@ __global__ __launch_bounds__(UpdateCfg<T>::type::THREADS, UpdateCfg<T>::min_wave
   // (DLAF_MI355X_KPHASE=1), default = the fixed summation order.
   __shared__ int next_s0;
   const int nslab = p.K / UpdateCfg<T>::type::BK;
+  int q = q0, tried = 1;
   for (;;) {
     if (threadIdx.x == 0) {
       next_item = atomicAdd(&mp.counters[q], 1u);
@@ -460,8 +512,15 @@ __global__ __launch_bounds__(UpdateCfg<T>::type::THREADS, UpdateCfg<T>::min_wave
     const int s0 = next_s0;
 #endif
     __syncthreads();
-    if (i >= per_q)
-      break;
+    if (i >= per_q) {
+      // own queue drained: help with the others (keeps the end of a launch balanced when the queues lost
+      // different numbers of workgroups to the reserved compute units)
+      if (!mp.steal || tried >= nq)
+        break;
+      ++tried;
+      q = (q + 1) % nq;
+      continue;
+    }
     if (mp.lockstep) {
       if (threadIdx.x == 0) {
         const unsigned need = (unsigned) (i / W) * W;  // every item of the earlier rounds
@@ -525,9 +584,21 @@ static bool aligned16(const void* ptr, long stride_elems) {
   return (reinterpret_cast<uintptr_t>(ptr) % 16 == 0) && ((stride_elems * (long) sizeof(T)) % 16 == 0);
 }
 
+// what the probe launch of update_kernels_init() found: XCDs and compute units per XCD (0: no probe, no exclusive mode)
+static int g_probe_xcds = 0, g_probe_cus_per_xcd = 0, g_probe_engines = 1;
+
+// DLAF_MI355X_STEAL=0: a persistent workgroup stops when its own queue is empty (A/B)
+static bool update_steal() {
+  static const bool on = [] {
+    const char* e = std::getenv("DLAF_MI355X_STEAL");
+    return e ? std::atoi(e) != 0 : true;
+  }();
+  return on;
+}
+
 template <class T>
 void launch_update(const UpdateArgs<T>& a, hipStream_t stream, int role, long max_blocks, unsigned* counters,
-                   bool counters_are_zero) {
+                   bool counters_are_zero, long excl_slots) {
   using Cfg = typename UpdateCfg<T>::type;
   if (a.il1 <= a.il0 || a.jl1 <= a.jl0 || a.K <= 0 || a.nb <= 0)
     return;
@@ -578,6 +649,24 @@ void launch_update(const UpdateArgs<T>& a, hipStream_t stream, int role, long ma
   mp.lockstep = 0;
   mp.kphase_ticks = 0;
   mp.counters = nullptr;
+  mp.excl_rank = 0;
+  mp.excl_budget = 0;
+  mp.steal = 0;
+  // Exclusive compute units only in whole rounds over the shader engines (one compute unit of every engine of every
+  // XCD per round: 64 slots on MI355X); otherwise -- or without a probe, or with lockstep pacing -- the launch leaves
+  // the slots free instead, spread by the dispatcher.
+  long excl_rank = 0;
+  if (excl_slots > 0) {
+    static const int per_cu = update_blocks_per_cu<T>();
+    const long round = (long) per_cu * g_probe_xcds * g_probe_engines;
+    if (g_probe_xcds > 0 && !update_lockstep() && excl_slots % round == 0 &&
+        (excl_slots / round) * g_probe_engines <= g_probe_cus_per_xcd / 2)
+      excl_rank = (excl_slots / round) * g_probe_engines;
+    else {
+      max_blocks = std::max<long>(8, max_blocks - excl_slots);
+      excl_slots = 0;
+    }
+  }
   if (max_blocks > 0 && counters != nullptr && mp.total > max_blocks) {
     grid = mp.xcd ? (max_blocks / 8) * 8 : max_blocks;  // equal number of workgroups per XCD range
     if (grid < 8)
@@ -586,6 +675,11 @@ void launch_update(const UpdateArgs<T>& a, hipStream_t stream, int role, long ma
     mp.counters = counters;
     mp.lockstep = update_lockstep() ? 1 : 0;
     mp.kphase_ticks = kphase_ticks<T>((int) (grid));
+    mp.steal = (update_steal() && !mp.lockstep) ? 1 : 0;
+    if (excl_rank > 0) {
+      mp.excl_rank = (int) excl_rank;
+      mp.excl_budget = (unsigned) excl_slots;
+    }
     if (!counters_are_zero)
       (void) hipMemsetAsync(counters, 0, 16 * sizeof(unsigned), stream);
   }
@@ -639,20 +733,112 @@ static void update_init_one() {
 #undef SET_ONE
 }
 
+// One probe launch: which (XCD, compute unit) pairs does a kernel of this process reach?  The compute units of each
+// XCD are ranked shader engine by shader engine (cu 0 of every engine first), so that "the first r" are spread over
+// the engines' dispatchers.
+static void probe_compute_units() {
+  const bool verbose = [] {
+    const char* e = std::getenv("DLAF_MI355X_PROBE_VERBOSE");
+    return e && std::atoi(e) != 0;
+  }();
+  auto note = [&](const char* what, hipError_t err) {
+    if (verbose)
+      std::fprintf(stderr, "[dlaf_mi355x] compute-unit probe: %s: %s\n", what, hipGetErrorString(err));
+    (void) hipGetLastError();
+  };
+  unsigned* seen = nullptr;
+  hipError_t err = hipMalloc(reinterpret_cast<void**>(&seen), 64 * sizeof(unsigned));
+  if (err != hipSuccess)
+    return note("hipMalloc", err);
+  unsigned h[64] = {};
+  err = hipMemset(seen, 0, sizeof(h));
+  if (err == hipSuccess) {
+    hipLaunchKernelGGL(cu_probe_kernel, dim3(8192), dim3(64), 48 * 1024, nullptr, seen);
+    err = hipGetLastError();
+  }
+  if (err == hipSuccess)
+    err = hipMemcpy(h, seen, sizeof(h), hipMemcpyDeviceToHost);
+  (void) hipFree(seen);
+  if (err != hipSuccess)
+    return note("probe launch", err);
+  static unsigned char rank[8][256];
+  std::memset(rank, 255, sizeof(rank));
+  int xcds = 0, min_cus = 1 << 30, max_engines = 0;
+  for (int x = 0; x < 8; ++x) {
+    std::vector<unsigned> keys;
+    for (unsigned key = 0; key < 256; ++key)
+      if (h[x * 8 + (key >> 5)] >> (key & 31) & 1u)
+        keys.push_back(key);
+    if (keys.empty())
+      continue;
+    ++xcds;
+    min_cus = std::min<int>(min_cus, (int) keys.size());
+    // key = se[7:5] sh[4] cu[3:0].  The workgroups of a dispatch go round-robin over the shader engines of an XCD
+    // and wait for "their" engine (measured: tools/overlap_bench.hip -- compute units vacated in two of the four
+    // engines leave a side kernel stuck behind the first workgroup that is routed to a full engine), so the rank
+    // order takes one compute unit of every engine in turn: ordinal within the engine first, engine second.
+    std::vector<unsigned> ord(keys.size());
+    int engines = 0;
+    for (size_t i = 0; i < keys.size(); ++i) {
+      unsigned n = 0;
+      bool first = true;
+      for (size_t j = 0; j < keys.size(); ++j)
+        if ((keys[j] >> 4) == (keys[i] >> 4)) {
+          if ((keys[j] & 15u) < (keys[i] & 15u))
+            ++n;
+          if (j < i)
+            first = false;
+        }
+      ord[i] = n;
+      engines += first ? 1 : 0;
+    }
+    std::vector<size_t> idx(keys.size());
+    for (size_t i = 0; i < idx.size(); ++i)
+      idx[i] = i;
+    std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) {
+      return std::make_pair(ord[a], keys[a] >> 4) < std::make_pair(ord[b], keys[b] >> 4);
+    });
+    for (size_t r = 0; r < idx.size(); ++r)
+      rank[x][keys[idx[r]]] = (unsigned char) std::min<size_t>(r, 254);
+    max_engines = std::max(max_engines, engines);
+    {
+      std::vector<unsigned> sorted(keys.size());
+      for (size_t r = 0; r < idx.size(); ++r)
+        sorted[r] = keys[idx[r]];
+      keys.swap(sorted);
+    }
+    if (verbose) {
+      std::fprintf(stderr, "[dlaf_mi355x] compute-unit probe: XCD %d: %zu compute units:", x, keys.size());
+      for (unsigned k : keys)
+        std::fprintf(stderr, " %u.%u.%u", k >> 5, (k >> 4) & 1u, k & 15u);
+      std::fprintf(stderr, "\n");
+    }
+  }
+  if (xcds == 0)
+    return note("no compute unit seen", hipSuccess);
+  err = hipMemcpyToSymbol(HIP_SYMBOL(g_cu_rank), rank, sizeof(rank));
+  if (err != hipSuccess)
+    return note("hipMemcpyToSymbol", err);
+  g_probe_xcds = xcds;
+  g_probe_cus_per_xcd = min_cus;
+  g_probe_engines = std::max(1, max_engines);
+}
+
 void update_kernels_init() {
   update_init_one<float>();
   update_init_one<double>();
   update_init_one<cfloat>();
   update_init_one<cdouble>();
+  probe_compute_units();
 }
 
-template void launch_update<float>(const UpdateArgs<float>&, hipStream_t, int, long, unsigned*, bool);
+template void launch_update<float>(const UpdateArgs<float>&, hipStream_t, int, long, unsigned*, bool, long);
 template int update_blocks_per_cu<float>();
-template void launch_update<double>(const UpdateArgs<double>&, hipStream_t, int, long, unsigned*, bool);
+template void launch_update<double>(const UpdateArgs<double>&, hipStream_t, int, long, unsigned*, bool, long);
 template int update_blocks_per_cu<double>();
-template void launch_update<cfloat>(const UpdateArgs<cfloat>&, hipStream_t, int, long, unsigned*, bool);
+template void launch_update<cfloat>(const UpdateArgs<cfloat>&, hipStream_t, int, long, unsigned*, bool, long);
 template int update_blocks_per_cu<cfloat>();
-template void launch_update<cdouble>(const UpdateArgs<cdouble>&, hipStream_t, int, long, unsigned*, bool);
+template void launch_update<cdouble>(const UpdateArgs<cdouble>&, hipStream_t, int, long, unsigned*, bool, long);
 template int update_blocks_per_cu<cdouble>();
 
 }  // namespace dlaf_mi355x

@@ -162,10 +162,11 @@ int triangular_solver_c(int ctx, char side, char uplo, char op, char diag, const
   const bool left = (side == 'L' || side == 'l');
   if (db.m < 0 || db.n < 0 || da.m != (left ? db.m : db.n))
     fatal("[dlaf_mi355x] triangular solver: A is %d x %d, B is %d x %d (side %c)\n", da.m, da.n, db.m, db.n, side);
-  // this build keeps square nb x nb device tiles: B's blocks must be the blocks of A
-  if (db.mb != da.nb || db.nb != da.nb)
-    fatal("[dlaf_mi355x] triangular solver: B's blocks (%d x %d) must equal A's (%d x %d)\n", db.mb, db.nb, da.mb,
-          da.nb);
+  // multipliable (util_matrix.h:123-143): B's block along the triangular dimension is A's; the other one is free
+  // (the device tiles stay square: the free dimension is re-cut locally, tile_matrix.hpp create_rhs)
+  if ((left ? db.mb : db.nb) != da.nb || db.mb < 1 || db.nb < 1)
+    fatal("[dlaf_mi355x] triangular solver: B's blocks (%d x %d) do not match A's (%d x %d) for side %c\n", db.mb, db.nb,
+          da.mb, da.nb, side);
   Grid& g = grid_from_context(ctx);
   for (const DLAF_descriptor* d : {&da, &db})
     if (d->isrc < 0 || d->isrc >= g.nprow || d->jsrc < 0 || d->jsrc >= g.npcol)
@@ -173,7 +174,7 @@ int triangular_solver_c(int ctx, char side, char uplo, char op, char diag, const
   DT al;
   std::memcpy(&al, alpha, sizeof(DT));
   return triangular_solver_host<DT>(&g, side, uplo, op, diag, al, reinterpret_cast<const DT*>(a), da.ld, da.isrc,
-                                    da.jsrc, reinterpret_cast<DT*>(b), db.ld, db.m, db.n, da.nb, db.isrc, db.jsrc);
+                                    da.jsrc, reinterpret_cast<DT*>(b), db.ld, db.m, db.n, da.nb, db.isrc, db.jsrc, left ? db.nb : db.mb);
 }
 
 // ScaLAPACK p?trsm argument list

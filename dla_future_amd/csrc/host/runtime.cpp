@@ -847,7 +847,15 @@ void DeviceMatrix<T>::factorize_async() {
       zero = sync_pool && next_update_slice < coop_sync_update_slices - 1;
       ++next_update_slice;
     }
-    launch_update(ua, s, role, reserve > 0 ? std::max<long>(8, bulk_slots - reserve) : 0, cnt, zero);
+    // DLAF_MI355X_EXCLUSIVE_CUS=1: the launch covers every slot and vacates whole compute units instead
+    static const bool exclusive = [] {
+      const char* e = std::getenv("DLAF_MI355X_EXCLUSIVE_CUS");
+      return e ? std::atoi(e) != 0 : false;
+    }();
+    if (reserve > 0 && exclusive)
+      launch_update(ua, s, role, bulk_slots, cnt, zero, reserve);
+    else
+      launch_update(ua, s, role, reserve > 0 ? std::max<long>(8, bulk_slots - reserve) : 0, cnt, zero);
     prof_end(pk, s, fl, by);
   };
 

@@ -220,10 +220,11 @@ void tile_gemm(char uplo, int m, int n, int k, const T* a, int lda, const T* b, 
 int grid_selftest(Grid& g, size_t bytes);
 
 // op(A) X = alpha B (side L) / X op(A) = alpha B (side R) on the grid, host operands (solver.cpp);
-// m x n: size of B, nb: the square block of A and B
+// m x n: size of B, nb: the square block of A = B's block along the triangular dimension, nb_free: B's block along
+// the other dimension (<= 0: nb)
 template <class T>
 int triangular_solver_host(Grid* g, char side, char uplo, char op, char diag, T alpha, const T* a, long lda, int a_isrc,
-                           int a_jsrc, T* b, long ldb, long m, long n, int nb, int b_isrc, int b_jsrc);
+                           int a_jsrc, T* b, long ldb, long m, long n, int nb, int b_isrc, int b_jsrc, int nb_free = 0);
 
 void solver_last_profile(double* ms, double* flops);
 

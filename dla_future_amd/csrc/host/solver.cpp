@@ -98,7 +98,7 @@ void solve_canonical(TileMatrix<T>& Td, TileMatrix<T>& Bd, bool upper, bool unit
   const bool dist = g->nranks > 1;
   const int nb = Bd.nb;
   const long nt = Bd.cols.nt();  // tiles along n
-  if (nt == 0 || Bd.rows.nt() == 0)
+  if (nt == 0 || Bd.rows_global == 0)
     return;
   const size_t tile_elems = Bd.tile_elems, tile_bytes = tile_elems * sizeof(T);
   const size_t winv_elems = (size_t) ((nb + kDiagBlock - 1) / kDiagBlock) * kDiagBlock * kDiagBlock;
@@ -196,13 +196,13 @@ void solve_canonical(TileMatrix<T>& Td, TileMatrix<T>& Bd, bool upper, bool unit
       tkk = Td.tile(Td.rows.local_of(k), Td.cols.local_of(k));
       wk = winv_all + q * winv_elems;
     }
-    if (need_diag && Bd.rows.P > 1) {
+    if (need_diag && Bd.row_P > 1) {
       // (own_diag implies need_diag: the owner sits in Bd's column k by the alignment requirement)
       if (own_diag) {
         DLAF_HIP_CHECK(hipMemcpyAsync(diag_ws[buf], tkk, tile_bytes, hipMemcpyDeviceToDevice, s_comm));
         DLAF_HIP_CHECK(hipMemcpyAsync(diag_ws[buf] + tile_elems, wk, winv_elems * sizeof(T), hipMemcpyDeviceToDevice, s_comm));
       }
-      tr->bcast(along_col, t_other.owner(k), Bd.rows.rank, diag_ws[buf], diag_ws[buf], diag_elems * sizeof(T), s_comm);
+      tr->bcast(along_col, t_other.owner(k), Bd.row_rank, diag_ws[buf], diag_ws[buf], diag_elems * sizeof(T), s_comm);
       tkk = diag_ws[buf];
       wk = diag_ws[buf] + tile_elems;
     }
@@ -223,8 +223,8 @@ void solve_canonical(TileMatrix<T>& Td, TileMatrix<T>& Bd, bool upper, bool unit
       T* dst = tpanel[buf];
       if (ncols > 0) {
         const T* src = have ? Td.tile(o.jl0, Td.cols.local_of(k)) : nullptr;
-        if (Bd.rows.P > 1)
-          tr->bcast(along_col, t_other.owner(k), Bd.rows.rank, src, dst, (size_t) ncols * tile_bytes, s_comm);
+        if (Bd.row_P > 1)
+          tr->bcast(along_col, t_other.owner(k), Bd.row_rank, src, dst, (size_t) ncols * tile_bytes, s_comm);
         else
           dst = const_cast<T*>(src);
       }
@@ -248,13 +248,13 @@ void solve_canonical(TileMatrix<T>& Td, TileMatrix<T>& Bd, bool upper, bool unit
           colp = Td.tile(il0, Td.cols.local_of(k));
         }
       }
-      if (Bd.rows.P > 1) {
+      if (Bd.row_P > 1) {
         tr->group_begin();
         for (long jl = o.jl0; jl < o.jl1; ++jl) {
           const long gj = Bd.cols.global_of(jl);
           const int root = Td.rows.owner(gj);
           const T* src = (Td.rows.rank == root) ? colp + (size_t) (Td.rows.local_of(gj) - il0) * tile_elems : nullptr;
-          tr->bcast(along_col, root, Bd.rows.rank, src, tpanel[buf] + (size_t) (jl - o.jl0) * tile_elems, tile_bytes, s_comm);
+          tr->bcast(along_col, root, Bd.row_rank, src, tpanel[buf] + (size_t) (jl - o.jl0) * tile_elems, tile_bytes, s_comm);
         }
         tr->group_end();
         o.base = tpanel[buf];
@@ -293,7 +293,7 @@ void solve_canonical(TileMatrix<T>& Td, TileMatrix<T>& Bd, bool upper, bool unit
     ua.jl1 = (int) j1;
     ua.nb = nb;
     ua.K = Bd.cols.tile_extent(k);
-    ua.pr = Bd.rows.P;
+    ua.pr = Bd.row_P;
     ua.ri = Bd.rows.shift();
     ua.pc = Bd.cols.P;
     ua.ci = Bd.cols.shift();
@@ -333,7 +333,7 @@ void solve_canonical(TileMatrix<T>& Td, TileMatrix<T>& Bd, bool upper, bool unit
       ta.ldb = nb;
       ta.il0 = 0;
       ta.il1 = (int) Bd.ltr;
-      ta.pr = Bd.rows.P;
+      ta.pr = Bd.row_P;
       ta.ri = Bd.rows.shift();
       ta.nb = nb;
       ta.nt = (int) Bd.rows.nt();
@@ -396,7 +396,7 @@ void solve_canonical(TileMatrix<T>& Td, TileMatrix<T>& Bd, bool upper, bool unit
     DLAF_HIP_CHECK(hipEventElapsedTime(&ms, ev_t0, ev_t1));
     g_last_sweep_ms = ms;
     // whole-grid algorithmic flops: rows x n^2 (x4 complex)
-    g_last_sweep_flops = (TypeInfo<T>::is_complex ? 4.0 : 1.0) * (double) Bd.rows.n * (double) Bd.cols.n * (double) Bd.cols.n;
+    g_last_sweep_flops = (TypeInfo<T>::is_complex ? 4.0 : 1.0) * (double) Bd.rows_global * (double) Bd.cols.n * (double) Bd.cols.n;
   }
   (void) hipEventDestroy(ev_t0);
   (void) hipEventDestroy(ev_t1);
@@ -429,7 +429,7 @@ void solver_last_profile(double* ms, double* flops) {
 // sides, ldb) on the grid; b is overwritten by the solution.
 template <class T>
 int triangular_solver_host(Grid* g, char side, char uplo, char op, char diag, T alpha, const T* a, long lda, int a_isrc,
-                           int a_jsrc, T* b, long ldb, long m, long n, int nb, int b_isrc, int b_jsrc) {
+                           int a_jsrc, T* b, long ldb, long m, long n, int nb, int b_isrc, int b_jsrc, int nb_free) {
   runtime_init();
   if (g->nranks > 1 && !g->transport && g->host_bcast)
     g->transport = make_host_transport(g->host_bcast, g->host_barrier, g->host_user);
@@ -463,7 +463,10 @@ int triangular_solver_host(Grid* g, char side, char uplo, char op, char diag, T 
   {
     TileMatrix<T> Td, Bd;
     Td.create(g, t_transposed, na, na, nb, a_isrc, a_jsrc);
-    Bd.create(g, left, m, n, nb, b_isrc, b_jsrc);
+    // B's blocks: nb along the triangular dimension (its rows for side = Left), nb_free along the other
+    if (nb_free <= 0)
+      nb_free = nb;
+    Bd.create_rhs(g, left, m, n, left ? nb : nb_free, left ? nb_free : nb, b_isrc, b_jsrc);
     Td.upload(a, lda, t_conj, false, T{}, s);
     // Left: B_dev = (alpha B)^H = conj(alpha) B^H (the relayout conjugates first, then scales)
     Bd.upload(b, ldb, left, true, left ? conj_el(alpha) : alpha, s);
@@ -631,12 +634,12 @@ int triangular_solver_device(char side, char uplo, char op, char diag, const voi
 }
 
 template int triangular_solver_host<float>(Grid*, char, char, char, char, float, const float*, long, int, int, float*,
-                                           long, long, long, int, int, int);
+                                           long, long, long, int, int, int, int);
 template int triangular_solver_host<double>(Grid*, char, char, char, char, double, const double*, long, int, int,
-                                            double*, long, long, long, int, int, int);
+                                            double*, long, long, long, int, int, int, int);
 template int triangular_solver_host<cfloat>(Grid*, char, char, char, char, cfloat, const cfloat*, long, int, int,
-                                            cfloat*, long, long, long, int, int, int);
+                                            cfloat*, long, long, long, int, int, int, int);
 template int triangular_solver_host<cdouble>(Grid*, char, char, char, char, cdouble, const cdouble*, long, int, int,
-                                             cdouble*, long, long, long, int, int, int);
+                                             cdouble*, long, long, long, int, int, int, int);
 
 }  // namespace dlaf_mi355x

@@ -27,6 +27,10 @@ struct TileMatrix {
   T* tiles = nullptr;
   T* staging = nullptr;
   bool owns = true;  // false: `tiles` belongs to somebody else (a view over a resident matrix)
+  // grid dimension the view's rows are spread over: processes, my coordinate, global extent.  They equal
+  // rows.P / rows.rank / rows.n unless the row axis has been localized (create_rhs).
+  int row_P = 1, row_rank = 0;
+  long rows_global = 0;
 
   // m_src x n_src: global size of the caller's matrix, (isrc, jsrc) its source process
   void create(Grid* g, bool transposed_, long m_src, long n_src, int nb_, int isrc, int jsrc, T* borrow = nullptr) {
@@ -42,6 +46,33 @@ struct TileMatrix {
     tile_elems = (size_t) nb * nb;
     owns = borrow == nullptr;
     tiles = owns ? tm_dev_alloc<T>((size_t) ltr * ltc * tile_elems) : borrow;
+    row_P = rows.P;
+    row_rank = rows.rank;
+    rows_global = rows.n;
+  }
+  // Right-hand sides of the triangular solver (view: rows = the free dimension, columns = the triangular one) with
+  // the reference's MB x NB blocks (solver/triangular.h:41-60: B's block along the triangular dimension is A's, the
+  // other one is free).  The rows of X T^H = B never interact, so WHICH rows a process holds is irrelevant to the
+  // sweep: the local rows -- whatever block size and source process spread them -- are re-cut into nb-row tiles of
+  // a one-process axis, and the device tiles stay square.
+  // m_src x n_src: the caller's matrix, mb_src x nb_src its blocks; nb_ = the block along the triangular dimension.
+  void create_rhs(Grid* g, bool transposed_, long m_src, long n_src, int mb_src, int nb_src, int isrc, int jsrc) {
+    grid = g;
+    transposed = transposed_;
+    Axis srow{m_src, mb_src, g->nprow, g->myrow, isrc};
+    Axis scol{n_src, nb_src, g->npcol, g->mycol, jsrc};
+    const Axis free_axis = transposed ? scol : srow;
+    cols = transposed ? srow : scol;
+    nb = cols.nb;
+    row_P = free_axis.P;
+    row_rank = free_axis.rank;
+    rows_global = free_axis.n;
+    rows = Axis{free_axis.local_size(), nb, 1, 0, 0};
+    ltr = rows.local_tiles();
+    ltc = cols.local_tiles();
+    tile_elems = (size_t) nb * nb;
+    owns = true;
+    tiles = tm_dev_alloc<T>((size_t) ltr * ltc * tile_elems);
   }
   ~TileMatrix() {
     if (tiles && owns)

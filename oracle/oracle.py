@@ -287,6 +287,41 @@ def gather(locs, n: int, nb: int, pr: int, pc: int, sr: int = 0, sc: int = 0, dt
     return a
 
 
+def _axis_members(n: int, nb: int, p: int, src: int):
+    """global element indices each process of a block-cyclic axis holds, in local order"""
+    g = np.arange(n)
+    owner = ((g // nb) + src) % p
+    return [g[owner == r] for r in range(p)]
+
+
+def scatter_rect(a: np.ndarray, mb: int, nb: int, pr: int, pc: int, sr: int = 0, sc: int = 0, extra_ld: int = 0):
+    """scatter() for MB x NB blocks (matrix.h: block size != square), element-index based."""
+    m, n = a.shape
+    ri, ci = _axis_members(m, mb, pr, sr), _axis_members(n, nb, pc, sc)
+    out = {}
+    for r in range(pr):
+        for c in range(pc):
+            rows, cols = len(ri[r]), len(ci[c])
+            store = np.full((max(1, rows) + extra_ld, max(cols, 1)), -77.0, dtype=a.dtype, order="F")
+            loc = store[:rows, :cols]
+            if rows and cols:
+                loc[:, :] = a[np.ix_(ri[r], ci[c])]
+            out[(r, c)] = loc
+    return out
+
+
+def gather_rect(locs, m: int, n: int, mb: int, nb: int, pr: int, pc: int, sr: int = 0, sc: int = 0, dtype=None) -> np.ndarray:
+    """Inverse of scatter_rect."""
+    dtype = dtype or next(iter(locs.values())).dtype
+    a = np.zeros((m, n), dtype=dtype, order="F")
+    ri, ci = _axis_members(m, mb, pr, sr), _axis_members(n, nb, pc, sc)
+    for r in range(pr):
+        for c in range(pc):
+            if len(ri[r]) and len(ci[c]):
+                a[np.ix_(ri[r], ci[c])] = locs[(r, c)][:len(ri[r]), :len(ci[c])]
+    return a
+
+
 # ----------------------------------------------------------------------------- algorithms
 def cholesky_local(uplo: str, a: np.ndarray, nb: int) -> int:
     """cholesky/impl.h:150-189 / :316-348 in place on a full (local) matrix."""

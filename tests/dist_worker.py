@@ -232,6 +232,31 @@ def main():
                             print(f"[dist_worker] solver FAILED {t} {side}{uplo}{op}{diag} {m}x{n} nb={nb} "
                                   f"grid {nprow}x{npcol}: max diff {md} tol {tol}", flush=True)
                         ok &= bool(good)
+            # B with MB x NB blocks (MB != NB) and a source process of its own along the free dimension
+            for t, (m, n, mb, nb) in [("d", (19, 25, 6, 5)), ("z", (15, 7, 3, 5)), ("d", (150, 70, 32, 48)), ("s", (7, 8, 2, 9))]:
+                dt = oracle.DTYPES[t]
+                alpha = dt(complex(-1.2, .7)) if t in "cz" else dt(-1.2)
+                for side, uplo, op, diag in itertools.product("LR", "LU", "NTC", "NU"):
+                    a, b, x = oracle.triangular_system(side, uplo, op, diag, alpha, m, n, dt)
+                    sr, sc = max(0, nprow - 1), min(1, npcol - 1)
+                    nba = mb if side == "L" else nb
+                    # B shares A's source process along the triangular dimension only
+                    bsr, bsc = (sr, 0) if side == "L" else (0, sc)
+                    la = np.asfortranarray(oracle.scatter(a, nba, nprow, npcol, sr, sc, extra_ld=1)[(grid.myrow, grid.mycol)])
+                    lb = np.asfortranarray(oracle.scatter_rect(b, mb, nb, nprow, npcol, bsr, bsc, extra_ld=2)[(grid.myrow, grid.mycol)])
+                    dlaf.triangular_solver(grid, side, uplo, op, diag, alpha, la, lb, nba, m=m, n=n, a_src=(sr, sc),
+                                           b_src=(bsr, bsc), b_block=(mb, nb))
+                    parts = [None] * dist.get_world_size()
+                    dist.all_gather_object(parts, (grid.myrow, grid.mycol, np.ascontiguousarray(lb)))
+                    if rank == 0:
+                        got = oracle.gather_rect({(r, c): np.asfortranarray(v) for r, c, v in parts}, m, n, mb, nb, nprow, npcol,
+                                                 bsr, bsc, dtype=dt)
+                        tol = 20 * (m + 1) * (8 if t in "cz" else 2) * oracle.eps_of(dt)
+                        good, md = oracle.check_near(x, got, tol, tol)
+                        if not good:
+                            print(f"[dist_worker] solver (rectangular blocks) FAILED {t} {side}{uplo}{op}{diag} {m}x{n} "
+                                  f"blocks {mb}x{nb} grid {nprow}x{npcol}: max diff {md} tol {tol}", flush=True)
+                        ok &= bool(good)
             # generalized_to_standard on the grid: the reference's distributed test (test_gen_to_std.cpp:85-113) --
             # analytic operands, non-zero source rank, abs tolerance 10 (m+1) error, the factor untouched -- plus
             # random operands against the oracle's restatement of GenToStd::call_L

@@ -9,10 +9,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 TYPES = ["s", "d", "c", "z"]
-# (m, n, nb): the reference's sizes with mb == nb (this build keeps square device tiles), plus sizes whose
-# tiles span several 64-wide blocks of the TRSM kernel and several 128-row strips
+# (m, n, nb): the reference's sizes with mb == nb, plus sizes whose tiles span several 64-wide blocks of the TRSM
+# kernel and several 128-row strips; RECT_SIZES (m, n, mb, nb): the reference's sizes with mb != nb
+# (test_triangular.cpp:59-65) plus larger ones -- A's block is mb for side = Left, nb for side = Right
 SIZES = [(0, 0, 1), (0, 2, 2), (7, 0, 2), (2, 2, 5), (10, 10, 3), (7, 7, 2), (3, 2, 7), (12, 3, 5), (15, 7, 3),
          (2, 3, 7), (4, 13, 5), (19, 25, 6), (150, 70, 32), (130, 257, 64), (200, 300, 128), (333, 129, 100)]
+RECT_SIZES = [(10, 10, 2, 3), (7, 7, 3, 2), (7, 6, 3, 2), (15, 7, 3, 5), (7, 8, 2, 9), (19, 25, 6, 5), (0, 2, 1, 2),
+              (7, 0, 2, 1), (150, 70, 32, 48), (130, 257, 64, 40), (200, 131, 24, 128)]
 
 
 @pytest.fixture(scope="module")
@@ -53,6 +56,34 @@ def test_triangular_solver_analytic(dlaf, grid, oracle, t, side):
         ok, md = oracle.check_near(x, sb[:m, :n], tol, tol)
         assert ok, (md, tol, m, n, nb, side, uplo, op, diag)
         assert (sb[m:, :] == 6.5).all() and np.array_equal(sa[:a.shape[0], :a.shape[1]], a)
+
+
+@pytest.mark.parametrize("t", TYPES)
+def test_triangular_solver_rectangular_blocks(dlaf, grid, oracle, t):
+    """B with MB x NB blocks, MB != NB (solver/triangular.h:41-60: only the block along the triangular dimension is
+    tied to A's): the reference's size list, analytic systems for the small ones, the oracle's trsm on random
+    operands for the multi-tile ones."""
+    dt = oracle.DTYPES[t]
+    cx = t in "cz"
+    alpha = dt(complex(-1.2, .7)) if cx else dt(-1.2)
+    rng = np.random.default_rng(5)
+    for (m, n, mb, nb), side, uplo, op, diag in itertools.product(RECT_SIZES, "LR", "LU", "NTC", "NU"):
+        na, nba = (m, mb) if side == "L" else (n, nb)
+        if max(m, n) <= 25:
+            a, b, x = oracle.triangular_system(side, uplo, op, diag, alpha, m, n, dt)
+        else:
+            a = rng.uniform(-1, 1, (na, na)) + (1j * rng.uniform(-1, 1, (na, na)) if cx else 0)
+            a = np.asfortranarray((a / na + 2 * np.eye(na)).astype(dt))
+            b = np.asfortranarray((rng.uniform(-1, 1, (m, n)) + (1j * rng.uniform(-1, 1, (m, n)) if cx else 0)).astype(dt))
+            x = b.copy(order="F")
+            oracle.trsm(side, uplo, op, diag, alpha, a, x)
+        sb = np.full((m + 2, max(1, n)), 6.5, dtype=dt, order="F")
+        sb[:m, :n] = b
+        dlaf.triangular_solver(grid, side, uplo, op, diag, alpha, np.asfortranarray(a), sb[:m, :n], nba, b_block=(mb, nb))
+        tol = 40 * (m + 1) * err_of(oracle, t)
+        ok, md = oracle.check_near(x, sb[:m, :n], tol, tol)
+        assert ok, (md, tol, m, n, mb, nb, side, uplo, op, diag)
+        assert (sb[m:, :] == 6.5).all()
 
 
 @pytest.mark.parametrize("t", TYPES)
