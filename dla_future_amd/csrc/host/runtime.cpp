@@ -847,10 +847,15 @@ void DeviceMatrix<T>::factorize_async() {
       zero = sync_pool && next_update_slice < coop_sync_update_slices - 1;
       ++next_update_slice;
     }
-    // DLAF_MI355X_EXCLUSIVE_CUS=1: the launch covers every slot and vacates whole compute units instead
+    // Reservations that are whole rounds over the shader engines (multiples of 64 slots on MI355X: the grid orders
+    // with a device-side transport at nb = 1024, the widened reservations near the end of the pairs order) are made
+    // as EXCLUSIVE compute units: the launch covers every slot and the workgroups that land on a reserved compute
+    // unit leave (kernels_update.hip), so the tile POTRF beside it runs at its stand-alone speed (0.87 instead of
+    // 2.3 ms per 1024-tile).  The others -- the 32 slots of the one-process orders, where 64 would cost the bulk
+    // launch 7 % -- stay free slots.  DLAF_MI355X_EXCLUSIVE_CUS=0: free slots always.
     static const bool exclusive = [] {
       const char* e = std::getenv("DLAF_MI355X_EXCLUSIVE_CUS");
-      return e ? std::atoi(e) != 0 : false;
+      return e ? std::atoi(e) != 0 : true;
     }();
     if (reserve > 0 && exclusive)
       launch_update(ua, s, role, bulk_slots, cnt, zero, reserve);
