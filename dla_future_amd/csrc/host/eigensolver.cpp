@@ -18,6 +18,8 @@
 //   of sweep group jb + 1 that overlap it, so all blocks with the same step - jb are independent: W2 = V^H E and
 //   E -= (V T) W2 run as two strided-batch GEMM launches per wavefront instead of two per block.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -158,6 +160,21 @@ int bt_band_to_tridiag_device(long n, int band, const T* v, long ldv, T* e, long
   const long nblk = (n + b - 1) / b;
   const size_t vblk = (size_t) 2 * b * b;
   const size_t nb2 = (size_t) nblk * nblk;
+  // DLAF_MI355X_BT_VERBOSE=1: wall time of the phases of this stage (synchronising: diagnosis only)
+  static const bool verbose = [] {
+    const char* e = std::getenv("DLAF_MI355X_BT_VERBOSE");
+    return e && std::atoi(e) != 0;
+  }();
+  auto t_last = std::chrono::steady_clock::now();
+  auto phase = [&](const char* what) {
+    if (!verbose)
+      return;
+    DLAF_HIP_CHECK(hipStreamSynchronize(s));
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[dlaf_mi355x] bt_band_to_tridiagonal: %-28s %8.2f ms\n", what,
+                 std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   T* vx = ealloc<T>(nb2 * vblk);
   T* wx = ealloc<T>(nb2 * vblk);
   T* sm = ealloc<T>(nb2 * (size_t) b * b);
@@ -165,6 +182,7 @@ int bt_band_to_tridiag_device(long n, int band, const T* v, long ldv, T* e, long
   T* taus = ealloc<T>(nb2 * (size_t) b);
   DLAF_HIP_CHECK(hipMemsetAsync(vx, 0, nb2 * vblk * sizeof(T), s));
   DLAF_HIP_CHECK(hipMemsetAsync(taus, 0, nb2 * (size_t) b * sizeof(T), s));
+  phase("allocations + memsets");
   launch_b2t_expand(v, ldv, n, b, vx, taus, s);
   const T one = make_host_el<T>(1.0), zero = make_host_el<T>(0.0), mone = make_host_el<T>(-1.0);
   {
@@ -210,6 +228,26 @@ int bt_band_to_tridiag_device(long n, int band, const T* v, long ldv, T* e, long
     g.sc = (long) vblk;
     launch_gemm(g, s);
   }
+  phase("expand, S, T factors, W");
+  // fp64, band 128: the fused kernel (kernels_bt.hip) applies a block to a column strip in one go, on E transposed;
+  // DLAF_MI355X_BT_FUSED=0: the two strided-batch products per wavefront (every type, every band)
+  static const bool fused_on = [] {
+    const char* e = std::getenv("DLAF_MI355X_BT_FUSED");
+    return e ? std::atoi(e) != 0 : true;
+  }();
+  const bool fused = fused_on && bt_fused_supported(b, sizeof(T), TypeInfo<T>::is_complex);
+  double *vt = nullptr, *wr = nullptr, *et = nullptr;
+  const long ldet = (ncols + 63) / 64 * 64;
+  if constexpr (std::is_same_v<T, double>) {
+    if (fused) {
+      vt = ealloc<double>(nb2 * vblk);
+      wr = ealloc<double>(nb2 * vblk);
+      launch_bt_relayout(vx, wx, vt, wr, (long) nb2, s);
+      et = ealloc<double>((size_t) ldet * n);
+      launch_bt_transpose(e, lde, n, ncols, et, ldet, s);
+    }
+  }
+  phase("relayout + transposition");
   // steps of sweep group jb (its first sweep has the most)
   auto steps_of = [&](long jb) -> long {
     const long sw = jb * b;
@@ -252,6 +290,11 @@ int bt_band_to_tridiag_device(long n, int band, const T* v, long ldv, T* e, long
       const long ib = 2 * jb + t;
       const long blk = jb * nblk + ib;
       const long r0 = 1 + ib * b;
+      if (fused) {
+        launch_bt_apply(vt + (size_t) blk * vblk, wr + (size_t) blk * vblk, (long) ((nblk + 2) * (long) vblk), (int) count, et, ldet,
+                        ncols, r0, (int) rows, s);
+        return;
+      }
       GemmArgs<T> g;  // W2 = V^H E
       g.M = b;
       g.N = (int) ncols;
@@ -297,9 +340,19 @@ int bt_band_to_tridiag_device(long n, int band, const T* v, long ldv, T* e, long
       run(q, 1, n - (1 + ib * b));
     }
   }
+  phase("wavefronts");
+  if constexpr (std::is_same_v<T, double>) {
+    if (fused)
+      launch_bt_transpose(et, ldet, ncols, n, e, lde, s);
+  }
   DLAF_HIP_CHECK(hipStreamSynchronize(s));
+  phase("transposition back");
   for (T* q : {vx, wx, sm, tm, taus, w2})
     DLAF_HIP_CHECK(hipFree(q));
+  for (double* q : {vt, wr, et})
+    if (q)
+      DLAF_HIP_CHECK(hipFree(q));
+  phase("frees");
   return 0;
 }
 
