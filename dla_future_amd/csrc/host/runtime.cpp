@@ -216,9 +216,18 @@ private:
 };
 }  // namespace
 
+// the transport of a grid that came with host callbacks: host-staged (default) or, DLAF_MI355X_TRANSPORT=peer, the
+// host-driven peer-copy transport whose control messages travel over the same callbacks (transport_peer.cpp)
+std::unique_ptr<Transport> make_callback_transport(dlaf_host_bcast_fn b, dlaf_host_barrier_fn bar, void* user) {
+  const char* e = std::getenv("DLAF_MI355X_TRANSPORT");
+  if (e && std::strcmp(e, "peer") == 0)
+    return make_peer_transport(b, bar, user);
+  return make_host_transport(b, bar, user);
+}
+
 Transport* grid_transport(Grid& g) {
   if (g.nranks > 1 && !g.transport && g.host_bcast)
-    g.transport = make_host_transport(g.host_bcast, g.host_barrier, g.host_user);
+    g.transport = make_callback_transport(g.host_bcast, g.host_barrier, g.host_user);
   if (g.transport && g.comm_log_on && dynamic_cast<RecordingTransport*>(g.transport.get()) == nullptr)
     g.transport = std::unique_ptr<Transport>(new RecordingTransport(std::move(g.transport), &g));
   if (g.transport) {
@@ -1000,12 +1009,15 @@ void DeviceMatrix<T>::factorize_async() {
     // MI355X.  DLAF_MI355X_SIDECAR_SLOTS fixes the reservation, DLAF_MI355X_LATE_BOOST=0 keeps it at its default.
     const bool slots_fixed = std::getenv("DLAF_MI355X_SIDECAR_SLOTS") != nullptr ||
                              (std::getenv("DLAF_MI355X_LATE_BOOST") && std::atoi(std::getenv("DLAF_MI355X_LATE_BOOST")) == 0);
+    // one rate table for both placement decisions below (in-situ measurements on MI355X): the bulk
+    // update, the panel TRSM per free slot beside it, the tile POTRF per (64-column block)^2 beside it
+    const bool cxt = TypeInfo<T>::is_complex, dbl = sizeof(real_t<T>) == 8;
+    const double r_bulk = dbl ? 66e12 : 118e12;
+    const double r_trsm_slot = (dbl ? 5e12 : 8e12) / 32.0;
+    const double t_potrf_blk2 = 11.3e-6 * (cxt ? 2.0 : 1.0);  // 2.9 ms per real 1024-tile
     auto pair_slots = [&](long k, const Step& bulk) -> long {
       if (slots_fixed || !bulk.valid || bulk.rest0 >= ltc)
         return sidecar_slots;
-      const bool cxt = TypeInfo<T>::is_complex, dbl = sizeof(real_t<T>) == 8;
-      const double r_bulk = dbl ? 66e12 : 118e12;
-      const double r_trsm_slot = (dbl ? 5e12 : 8e12) / 32.0;  // per free slot, beside the bulk
       double fl_b = 0, by;
       for (long jl = bulk.rest0; jl < ltc; ++jl) {
         double f;
@@ -1016,7 +1028,7 @@ void DeviceMatrix<T>::factorize_async() {
       const double below = (double) std::max<long>(0, n - (k + 1) * (long) nb) + (double) std::max<long>(0, n - (k + 2) * (long) nb);
       const double fl_t = cxf * (double) nb * nb * below;
       const double nblk = (double) nb / kDiagBlock;
-      const double t_potrf = 2.0 * nblk * nblk * 11.3e-6 * (cxt ? 2.0 : 1.0);  // 2.9 ms per 1024-tile beside the bulk
+      const double t_potrf = 2.0 * nblk * nblk * t_potrf_blk2;
       auto t_of = [&](long sl) {
         const double share = (double) sl / (double) bulk_slots;
         return std::max(fl_b / (r_bulk * (1.0 - share)), t_potrf + fl_t / (r_trsm_slot * (double) sl));
@@ -1072,13 +1084,12 @@ void DeviceMatrix<T>::factorize_async() {
           colfl[(size_t) (jl - prev.rest0)] = f;
           total += f;
         }
-        // beside-the-bulk rates per free slot (in situ, fp64 MI355X; other types scale alike on both sides)
         const double cxf = TypeInfo<T>::is_complex ? 4.0 : 1.0;
         const double below1 = (double) std::max<long>(0, n - (k + 1) * (long) nb), below2 = (double) std::max<long>(0, n - (k + 2) * (long) nb);
         const double fl_chain = cxf * (double) nb * nb * (below1 + below2) + cxf * 2.0 * (double) nb * nb * below1;  // 2 TRSM + U1
         const double nblk = (double) nb / kDiagBlock;
-        const double t_chain = 2.0 * nblk * nblk * 11.3e-6 + fl_chain / (5e12 * (double) slots / 32.0);
-        const double t_bulk = total / (66e12 * (1.0 - (double) slots / (double) bulk_slots));
+        const double t_chain = 2.0 * nblk * nblk * t_potrf_blk2 + fl_chain / (r_trsm_slot * (double) slots);
+        const double t_bulk = total / (r_bulk * (1.0 - (double) slots / (double) bulk_slots));
         const char* force = std::getenv("DLAF_MI355X_U1");  // "main" / "panel": fix the placement
         u1_on_main = force ? std::strcmp(force, "main") == 0 : t_bulk < t_chain;
         if (u1_on_main) {

@@ -106,6 +106,11 @@ void rccl_get_unique_id(void* out128);
 Transport* grid_transport(Grid& g);
 std::unique_ptr<Transport> make_host_transport(dlaf_host_bcast_fn bcast, dlaf_host_barrier_fn barrier,
                                                void* user);
+// host-driven peer copies (hipIpc mappings + interprocess events), control messages over the host callbacks
+std::unique_ptr<Transport> make_peer_transport(dlaf_host_bcast_fn bcast, dlaf_host_barrier_fn barrier,
+                                               void* user);
+std::unique_ptr<Transport> make_callback_transport(dlaf_host_bcast_fn bcast, dlaf_host_barrier_fn barrier,
+                                                   void* user);
 
 // ------------------------------------------------------------------------------------------------
 // Device matrix in tile layout + the per-factorization workspaces.

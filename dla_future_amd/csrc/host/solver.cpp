@@ -293,7 +293,7 @@ void solve_canonical(TileMatrix<T>& Td, TileMatrix<T>& Bd, bool upper, bool unit
     ua.jl1 = (int) j1;
     ua.nb = nb;
     ua.K = Bd.cols.tile_extent(k);
-    ua.pr = Bd.row_P;
+    ua.pr = Bd.rows.P;
     ua.ri = Bd.rows.shift();
     ua.pc = Bd.cols.P;
     ua.ci = Bd.cols.shift();
@@ -333,7 +333,7 @@ void solve_canonical(TileMatrix<T>& Td, TileMatrix<T>& Bd, bool upper, bool unit
       ta.ldb = nb;
       ta.il0 = 0;
       ta.il1 = (int) Bd.ltr;
-      ta.pr = Bd.row_P;
+      ta.pr = Bd.rows.P;
       ta.ri = Bd.rows.shift();
       ta.nb = nb;
       ta.nt = (int) Bd.rows.nt();
@@ -431,8 +431,7 @@ template <class T>
 int triangular_solver_host(Grid* g, char side, char uplo, char op, char diag, T alpha, const T* a, long lda, int a_isrc,
                            int a_jsrc, T* b, long ldb, long m, long n, int nb, int b_isrc, int b_jsrc, int nb_free) {
   runtime_init();
-  if (g->nranks > 1 && !g->transport && g->host_bcast)
-    g->transport = make_host_transport(g->host_bcast, g->host_barrier, g->host_user);
+  (void) grid_transport(*g);
   if (g->nranks > 1 && !g->transport)
     fatal("[dlaf_mi355x] grid with %d ranks has no transport\n", g->nranks);
   if (m == 0 || n == 0)

@@ -85,6 +85,18 @@ def test_distributed_cholesky_classic_schedule(nprow, npcol, order):
                                                                "DIST_WORKER_CHOLESKY_ONLY": "1"})
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("nprow,npcol,order,cholesky_only", [(1, 2, "R", "0"), (2, 2, "C", "1"), (1, 3, "R", "1")])
+def test_distributed_peer_copy_transport(nprow, npcol, order, cholesky_only):
+    """DLAF_MI355X_TRANSPORT=peer: every broadcast of the executor is a device-to-device copy out of the root's
+    hipIpc-mapped memory, ordered by interprocess events (csrc/host/transport_peer.cpp); the control messages travel
+    over the gloo callback.  Same worker, same checks as the host-staged runs; the 1 x 2 case runs the widenings too
+    (solver, gen_to_std, eigensolver stages: temporaries allocated and freed per call; the whole worker on 2 x 2 passes
+    as well, 63 s)."""
+    launch("gpu", nprow, npcol, order, timeout=600, extra_env={"DLAF_MI355X_TRANSPORT": "peer",
+                                                               "DIST_WORKER_CHOLESKY_ONLY": cholesky_only})
+
+
 RCCL_SINGLE = r"""
 import sys, numpy as np
 sys.path.insert(0, %r)
