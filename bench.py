@@ -52,8 +52,9 @@ def parse():
                    help="skip the extra (untimed-for-the-metric) whole-eigensolver line at N = 1")
     p.add_argument("--r2b-n", type=int, default=20480)
     p.add_argument("--r2b-nb", type=int, default=512)
-    p.add_argument("--transport", default="rccl", choices=["rccl", "host"],
-                   help="host = gloo-staged broadcasts: lets several ranks rehearse the N > 1 path on ONE GPU")
+    p.add_argument("--transport", default="rccl", choices=["rccl", "host", "peer"],
+                   help="host = gloo-staged broadcasts: lets several ranks rehearse the N > 1 path on ONE GPU; "
+                        "peer = device-to-device copies out of hipIpc-mapped staging buffers, control messages over gloo")
     return p.parse_args()
 
 
@@ -189,6 +190,8 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    if args.transport == "peer":
+        os.environ["DLAF_MI355X_TRANSPORT"] = "peer"   # read when the grid's transport is built (csrc/host/transport_peer.cpp)
     import dla_future_amd as dlaf
     dlaf.initialize()
     nprow, npcol = GRIDS.get(world, (1, world))

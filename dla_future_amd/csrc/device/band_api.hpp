@@ -128,12 +128,11 @@ void launch_zero_rows(T* x, long ldx, long nrows, int ncols, hipStream_t stream)
 
 // ------------------------------------------------------------------------------------------
 // Fused application of the reflector blocks of bt_band_to_tridiagonal (kernels_bt.hip): fp64, band 128.
-//   relayout: per 2b x b block, vt = V^T (row r at r * b), wr = W cut into 16-row tiles ([tile][c][16])
 //   transpose: dst[c + r * ldd] = src[r + c * lds] (the stage works on E transposed)
-//   apply: blocks q = 0 .. nblocks-1 of one wavefront (operands at vt/wr + q * blk_stride, rows
+//   apply: blocks q = 0 .. nblocks-1 of one wavefront (V^T with b-element rows at vt + q * blk_stride, W column-major
+//          with 2b rows at wr + q * blk_stride, rows
 //          [r0_first + q * 2b, + rows) of E) on every 64-column strip of et (ncols columns, ldet >= ncols)
 bool bt_fused_supported(int band, size_t elem_size, bool is_complex);
-void launch_bt_relayout(const double* v, const double* w, double* vt, double* wr, long nblocks, hipStream_t stream);
 void launch_bt_transpose(const double* src, long lds_, long rows, long cols, double* dst, long ldd, hipStream_t stream);
 void launch_bt_apply(const double* vt, const double* wr, long blk_stride, int nblocks, double* et, long ldet, long ncols,
                      long r0_first, int rows, hipStream_t stream);

@@ -472,9 +472,10 @@ constexpr int kTfMax = 1024;  // 4 rows of 1024 complex doubles = 64 KiB of LDS
 
 // T(j, j) = tau_j,  t_j = T(0:j, 0:j) (-tau_j S(0:j, j))  (t_factor_impl.h:60-131), written ROW-wise: row i of T needs
 // only itself, S and taus --  T(i, j) = -tau_j sum_{l=i}^{j-1} T(i, l) S(l, j)  for j > i -- so the k rows are k
-// independent waves (4 per workgroup), each a chain of k - i dot products whose operand column S(:, j+1) is fetched
-// while the dot product of column j is being reduced.  The row lives in LDS (one value per column).
-constexpr int kTfU = 8;  // prefetch registers per lane: columns of up to 64 * kTfU rows (larger k: no prefetch)
+// independent waves (4 per workgroup), each a chain of k - i dot products whose operand columns of S are fetched a
+// chunk ahead.  The row and a copy of the taus live in LDS.  (A thread-per-row variant without any cross-lane
+// reduction -- scalar loads of S, the row in LDS -- was built and measured slower: a dependent chain of k^2 / 2
+// LDS-fed FMAs per thread, 0.7 instead of 0.4 ms for k = 128.)
 
 template <class T>
 __device__ __forceinline__ T wave_sum(T v) {
@@ -492,7 +493,8 @@ __device__ __forceinline__ T wave_sum(T v) {
   return v;
 }
 
-template <class T>
+// kTfU: registers per lane and column (columns of up to 64 * kTfU rows), kTfD: columns in flight
+template <class T, int kTfU, int kTfD>
 __global__ __launch_bounds__(kThreads) void tfactor_kernel(const T* s, long lds_, const T* taus, int k, T* t, long ldt,
                                                            long bs, long btau, long bt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tf_raw[];
@@ -503,46 +505,69 @@ __global__ __launch_bounds__(kThreads) void tfactor_kernel(const T* s, long lds_
   const int i = blockIdx.x * (kThreads / 64) + wave;
   if (i >= k)
     return;  // (no workgroup barrier below: waves are independent)
-  T* row = reinterpret_cast<T*>(tf_raw) + (size_t) wave * k;
+  // per wave: the row of T being built and a copy of the taus (a global load of taus[j] inside the sequential loop
+  // costs a memory latency per step)
+  T* row = reinterpret_cast<T*>(tf_raw) + (size_t) wave * 2 * k;
+  T* tau_s = row + k;
   for (int j = lane; j < i; j += 64)
     t[i + (long) j * ldt] = zero_el<T>();
+  for (int j = i + lane; j < k; j += 64)
+    tau_s[j] = taus[j];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   if (lane == 0)
-    row[i] = taus[i];
+    row[i] = tau_s[i];
   const bool pre = (k - i) <= 64 * kTfU;
-  T nxt[kTfU];
-  auto fetch = [&](int j) {
+  if (pre) {
+    // columns of S in chunks of kTfD, the next chunk in flight while this one is consumed: a step then costs a wave
+    // reduction and an LDS round trip instead of a global-memory latency (0.5 ms -> tens of microseconds for k = 128)
+    T cur[kTfD][kTfU], nxt[kTfD][kTfU];
+    auto fetch = [&](int j0, T (&dst)[kTfD][kTfU]) {
 #pragma unroll
-    for (int u = 0; u < kTfU; ++u) {
-      const int l = i + lane + 64 * u;
-      nxt[u] = (l < j) ? s[l + (long) j * lds_] : zero_el<T>();
-    }
-  };
-  if (pre && i + 1 < k)
-    fetch(i + 1);
-  for (int j = i + 1; j < k; ++j) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    T acc = zero_el<T>();
-    if (pre) {
-      T cur[kTfU];
+      for (int d = 0; d < kTfD; ++d)
 #pragma unroll
-      for (int u = 0; u < kTfU; ++u)
-        cur[u] = nxt[u];
-      if (j + 1 < k)
-        fetch(j + 1);
+        for (int u = 0; u < kTfU; ++u) {
+          const int j = j0 + d, l = i + lane + 64 * u;
+          dst[d][u] = (j < k && l < j) ? s[l + (long) j * lds_] : zero_el<T>();
+        }
+    };
+    fetch(i + 1, nxt);
+    for (int j0 = i + 1; j0 < k; j0 += kTfD) {
 #pragma unroll
-      for (int u = 0; u < kTfU; ++u) {
-        const int l = i + lane + 64 * u;
-        if (l < j)
-          acc = el_add(acc, el_mul(row[l], cur[u]));
+      for (int d = 0; d < kTfD; ++d)
+#pragma unroll
+        for (int u = 0; u < kTfU; ++u)
+          cur[d][u] = nxt[d][u];
+      if (j0 + kTfD < k)
+        fetch(j0 + kTfD, nxt);
+#pragma unroll
+      for (int d = 0; d < kTfD; ++d) {
+        const int j = j0 + d;
+        if (j < k) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          T acc = zero_el<T>();
+#pragma unroll
+          for (int u = 0; u < kTfU; ++u) {
+            const int l = i + lane + 64 * u;
+            if (l < j)
+              acc = el_add(acc, el_mul(row[l], cur[d][u]));
+          }
+          acc = wave_sum(acc);
+          if (lane == 0)
+            row[j] = el_neg(el_mul(tau_s[j], acc));
+        }
       }
     }
-    else {
+  }
+  else {
+    for (int j = i + 1; j < k; ++j) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      T acc = zero_el<T>();
       for (int l = i + lane; l < j; l += 64)
         acc = el_add(acc, el_mul(row[l], s[l + (long) j * lds_]));
+      acc = wave_sum(acc);
+      if (lane == 0)
+        row[j] = el_neg(el_mul(tau_s[j], acc));
     }
-    acc = wave_sum(acc);
-    if (lane == 0)
-      row[j] = el_neg(el_mul(taus[j], acc));
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   for (int j = i + lane; j < k; j += 64)
@@ -1191,8 +1216,20 @@ void launch_tfactor(const T* s, long lds_, const T* taus, int k, T* t, long ldt,
     abort();
   }
   const int rows_per_wg = kThreads / 64;
-  hipLaunchKernelGGL((tfactor_kernel<T>), dim3((unsigned) ((k + rows_per_wg - 1) / rows_per_wg), (unsigned) batch),
-                     dim3(kThreads), (size_t) rows_per_wg * k * sizeof(T), stream, s, lds_, taus, k, t, ldt, bs, btau, bt);
+  auto go = [&](auto utag, auto dtag) {
+    hipLaunchKernelGGL((tfactor_kernel<T, decltype(utag)::value, decltype(dtag)::value>),
+                       dim3((unsigned) ((k + rows_per_wg - 1) / rows_per_wg), (unsigned) batch), dim3(kThreads),
+                       (size_t) rows_per_wg * 2 * k * sizeof(T), stream, s, lds_, taus, k, t, ldt, bs, btau, bt);
+  };
+  using std::integral_constant;
+  if (k <= 64)
+    go(integral_constant<int, 1>{}, integral_constant<int, 8>{});
+  else if (k <= 128)
+    go(integral_constant<int, 2>{}, integral_constant<int, 8>{});
+  else if (k <= 256)
+    go(integral_constant<int, 4>{}, integral_constant<int, 4>{});
+  else
+    go(integral_constant<int, 8>{}, integral_constant<int, 2>{});
 }
 
 template <class T>

@@ -12,8 +12,9 @@
 //     group read 128 contiguous bytes), and that map IS the B-operand map of the next product (k = 4v + g): the
 //     window is the operand of W2 = V^H E and the accumulator of E -= W W2 without ever moving;
 //   * W2 (b x 16 per wave) lives in accumulators and is fed back as the B operand the same way;
-//   * V^H and W stream through a ring of LDS stages in 16-row chunks (direct-to-LDS loads, shared by the four waves
-//     of the workgroup, which own 16 columns each and never exchange data);
+//   * V^T (written in that form by the expansion kernel) and W stream through a ring of LDS stages in 16-row chunks
+//     (direct-to-LDS loads, shared by the four waves of the workgroup, which own 16 columns each and never exchange
+//     data);
 //   * the 16 x 16 tiles of V (column c non-zero in rows [c, c + b)) and W = V T (rows [0, c + b)) that are zero by
 //     construction are skipped: 688 instead of 1024 MFMAs per block and wave.
 // E is read once and written once per block; nothing else goes through HBM (V and W of a block are shared by the
@@ -33,31 +34,6 @@ constexpr int kBtVtLd = kBtB + 16;        // LDS row stride of a V^H chunk (elem
 constexpr int kBtStage = 16 * kBtVtLd;    // elements of a ring stage (a W chunk needs 16 * 128)
 constexpr int kBtStages = 4;
 
-// vt[blk][r * b + c] = v[blk][r + c * 2b];  wr[blk][((r / 16) * b + c) * 16 + r % 16] = w[blk][r + c * 2b]
-__global__ __launch_bounds__(256) void bt_relayout_kernel(const double* __restrict__ v, const double* __restrict__ w,
-                                                          double* __restrict__ vt, double* __restrict__ wr) {
-  __shared__ double tile[32][33];
-  const size_t blk = blockIdx.y;
-  const double* vs = v + blk * (size_t) (kBtRows * kBtB);
-  const double* ws = w + blk * (size_t) (kBtRows * kBtB);
-  double* vd = vt + blk * (size_t) (kBtRows * kBtB);
-  double* wd = wr + blk * (size_t) (kBtRows * kBtB);
-  // blockIdx.x: 32 x 32 sub-tile (rt of 8 row groups, ct of 4 column groups)
-  const int rt = blockIdx.x % (kBtRows / 32), ct = blockIdx.x / (kBtRows / 32);
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  for (int cc = ty; cc < 32; cc += 8) {
-    const int r = rt * 32 + tx, c = ct * 32 + cc;
-    tile[cc][tx] = vs[r + (size_t) c * kBtRows];
-    const double wv = ws[r + (size_t) c * kBtRows];
-    wd[((size_t) (r >> 4) * kBtB + c) * 16 + (r & 15)] = wv;
-  }
-  __syncthreads();
-  for (int rr = ty; rr < 32; rr += 8) {
-    const int r = rt * 32 + rr, c = ct * 32 + tx;
-    vd[(size_t) r * kBtB + c] = tile[tx][rr];
-  }
-}
-
 // dst[c + r * ldd] = src[r + c * lds_] (rows x cols source, column-major) -- both directions of the stage's transposition
 __global__ __launch_bounds__(256) void bt_transpose_kernel(const double* __restrict__ src, long lds_, long rows, long cols,
                                                            double* __restrict__ dst, long ldd) {
@@ -73,7 +49,8 @@ __global__ __launch_bounds__(256) void bt_transpose_kernel(const double* __restr
       dst[(c0 + tx) + (r0 + rr) * ldd] = tile[tx][rr];
 }
 
-// One workgroup: block q = blockIdx.x / nstrips of the launch (V^H at vt + q * blk_stride, W at wr + q * blk_stride,
+// One workgroup: block q = blockIdx.x / nstrips of the launch (V^T, b-element rows, at vt + q * blk_stride; W, column-major
+// with 2b rows, at wr + q * blk_stride;
 // rows [r0 + q * 2b, + rows) of E), strip blockIdx.x % nstrips (64 columns); wave w: 16 columns.
 __global__ __launch_bounds__(256, 2) void bt_apply_kernel(const double* __restrict__ vt, const double* __restrict__ wr,
                                                           long blk_stride, double* __restrict__ et, long ldet, long ncols,
@@ -112,8 +89,10 @@ __global__ __launch_bounds__(256, 2) void bt_apply_kernel(const double* __restri
     else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int piece = wave * 4 + i;  // 1 KiB pieces of the 16 KiB chunk
-        const double* ga = wrb + (size_t) (t - kBtRT) * (16 * kBtB) + piece * 128 + lane * 2;
+        // 1 KiB pieces of the 16 KiB chunk [c][16 rows]: eight columns of W (column-major, 2b rows) per piece,
+        // 128 contiguous bytes of each
+        const int piece = wave * 4 + i;
+        const double* ga = wrb + (size_t) (piece * 8 + (lane >> 3)) * kBtRows + (t - kBtRT) * 16 + (lane & 7) * 2;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) ga,
                                          (__attribute__((address_space(3))) void*) (dst + piece * 128), 16, 0, 0);
       }
@@ -230,18 +209,6 @@ __global__ __launch_bounds__(256, 2) void bt_apply_kernel(const double* __restri
 
 bool bt_fused_supported(int band, size_t elem_size, bool is_complex) {
   return band == kBtB && elem_size == sizeof(double) && !is_complex;
-}
-
-void launch_bt_relayout(const double* v, const double* w, double* vt, double* wr, long nblocks, hipStream_t stream) {
-  if (nblocks <= 0)
-    return;
-  // (grid y is limited to 65535: cut the block range)
-  for (long b0 = 0; b0 < nblocks; b0 += 32768) {
-    const long cnt = std::min<long>(32768, nblocks - b0);
-    const size_t off = (size_t) b0 * kBtRows * kBtB;
-    hipLaunchKernelGGL(bt_relayout_kernel, dim3((kBtRows / 32) * (kBtB / 32), (unsigned) cnt), dim3(256), 0, stream, v + off,
-                       w + off, vt + off, wr + off);
-  }
 }
 
 void launch_bt_transpose(const double* src, long lds_, long rows, long cols, double* dst, long ldd, hipStream_t stream) {

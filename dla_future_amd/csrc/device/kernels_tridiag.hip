@@ -908,7 +908,7 @@ size_t b2t_reg_lds_bytes() {
 // one workgroup per block (ib, jb): well-formed 2 b x b image + taus
 template <class T>
 __global__ __launch_bounds__(kThreads) void b2t_expand_kernel(const T* vout, long ldv, long n, int b, int nblk, T* vx,
-                                                              T* taus) {
+                                                              T* taus, int transposed) {
   using R = real_t<T>;
   const int ib = blockIdx.x, jb = blockIdx.y;
   const long blk = (long) jb * nblk + ib;
@@ -936,7 +936,8 @@ __global__ __launch_bounds__(kThreads) void b2t_expand_kernel(const T* vout, lon
           v = vout[(long) ib * b + i + sw * ldv];
       }
     }
-    out[e] = v;
+    // transposed: the image of V^T (element (r, k) at k + r b), what the fused back-transformation streams
+    out[transposed ? k + (long) r * b : e] = v;
   }
   for (int k = threadIdx.x; k < b; k += kThreads) {
     const long sw = (long) jb * b + k;
@@ -1086,19 +1087,19 @@ void launch_band_to_tridiag(T* band, long n, int b, T* vout, long ldv, unsigned*
 }
 
 template <class T>
-void launch_b2t_expand(const T* vout, long ldv, long n, int b, T* vx, T* taus, hipStream_t stream) {
+void launch_b2t_expand(const T* vout, long ldv, long n, int b, T* vx, T* taus, hipStream_t stream, bool transposed) {
   const int nblk = (int) ((n + b - 1) / b);
   if (nblk <= 0)
     return;
   hipLaunchKernelGGL((b2t_expand_kernel<T>), dim3((unsigned) nblk, (unsigned) nblk), dim3(kThreads), 0, stream, vout, ldv, n,
-                     b, nblk, vx, taus);
+                     b, nblk, vx, taus, transposed ? 1 : 0);
 }
 
 #define INST(T)                                                                                                      \
   template void launch_band_extract<T>(const T*, long, int, int, int, int, int, long, int, T*, hipStream_t);        \
   template void launch_tridiag_extract<T>(const T*, long, int, real_t<T>*, real_t<T>*, hipStream_t);                \
   template void launch_band_to_tridiag<T>(T*, long, int, T*, long, unsigned*, int*, hipStream_t);                   \
-  template void launch_b2t_expand<T>(const T*, long, long, int, T*, T*, hipStream_t);                                \
+  template void launch_b2t_expand<T>(const T*, long, long, int, T*, T*, hipStream_t, bool);                                \
   template void launch_rows_to_tiles<T>(const T*, long, long, long, int, int, int, long, long, T*, hipStream_t);
 INST(float)
 INST(double)

@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256) void dc_secular_kernel(DcMergeArgs<R> p) {
     return;
   const R rho = h.rho;
   const R* dsec = p.dsec + mg.off;
-  const R* zsec = p.zsec + mg.off;
+  (void) p.zsec;
   R* col = p.dlt + mg.off + (mg.off + j) * p.ldq;  // k entries
   R* z2 = p.z2 + mg.off;                           // z_i^2, written by dc_z2_kernel
   R lo, hi;

@@ -44,7 +44,7 @@ int b2t_max_band();
 // ib - jb (bt_band_to_tridiag.h:64-77).  Its well-formed image: vx + blk * 2 b * b, 2 b x b (ld 2 b), column k with its
 // 1 in row k; taus + blk * b.  blk = jb * nblk + ib, nblk = ceil(n / b).  Columns that hold no reflector are zero.
 template <class T>
-void launch_b2t_expand(const T* vout, long ldv, long n, int b, T* vx, T* taus, hipStream_t stream);
+void launch_b2t_expand(const T* vout, long ldv, long n, int b, T* vx, T* taus, hipStream_t stream, bool transposed = false);
 
 // ------------------------------------------------------------------------------------------ eigenvector plumbing
 // e[r + cl * lde] = (T) z[r + gc * ldz]: the local columns cl of a block-cyclic column axis (pc processes, this one at

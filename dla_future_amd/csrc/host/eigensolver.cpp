@@ -183,19 +183,27 @@ int bt_band_to_tridiag_device(long n, int band, const T* v, long ldv, T* e, long
   DLAF_HIP_CHECK(hipMemsetAsync(vx, 0, nb2 * vblk * sizeof(T), s));
   DLAF_HIP_CHECK(hipMemsetAsync(taus, 0, nb2 * (size_t) b * sizeof(T), s));
   phase("allocations + memsets");
-  launch_b2t_expand(v, ldv, n, b, vx, taus, s);
+  // fp64, band 128: the fused kernel (kernels_bt.hip) applies a block to a column strip in one go, on E transposed, and
+  // streams V^T: the expansion writes that image directly (S = V^H V and W = V T take it as their operand);
+  // DLAF_MI355X_BT_FUSED=0: the two strided-batch products per wavefront (every type, every band)
+  static const bool fused_on = [] {
+    const char* e = std::getenv("DLAF_MI355X_BT_FUSED");
+    return e ? std::atoi(e) != 0 : true;
+  }();
+  const bool fused = fused_on && bt_fused_supported(b, sizeof(T), TypeInfo<T>::is_complex);
+  launch_b2t_expand(v, ldv, n, b, vx, taus, s, fused);
   const T one = make_host_el<T>(1.0), zero = make_host_el<T>(0.0), mone = make_host_el<T>(-1.0);
   {
-    GemmArgs<T> g;  // S = V^H V
+    GemmArgs<T> g;  // S = V^H V  (fused: vx holds V^T, S = V^T (V^T)^H for the real types of that path)
     g.M = b;
     g.N = b;
     g.K = 2 * b;
     g.a = vx;
-    g.lda = 2 * b;
-    g.opa = 'C';
+    g.lda = fused ? b : 2 * b;
+    g.opa = fused ? 'N' : 'C';
     g.b = vx;
-    g.ldb = 2 * b;
-    g.opb = 'N';
+    g.ldb = fused ? b : 2 * b;
+    g.opb = fused ? 'C' : 'N';
     g.c = sm;
     g.ldc = b;
     g.alpha = one;
@@ -213,8 +221,8 @@ int bt_band_to_tridiag_device(long n, int band, const T* v, long ldv, T* e, long
     g.N = b;
     g.K = b;
     g.a = vx;
-    g.lda = 2 * b;
-    g.opa = 'N';
+    g.lda = fused ? b : 2 * b;
+    g.opa = fused ? 'C' : 'N';
     g.b = tm;
     g.ldb = b;
     g.opb = 'N';
@@ -229,25 +237,15 @@ int bt_band_to_tridiag_device(long n, int band, const T* v, long ldv, T* e, long
     launch_gemm(g, s);
   }
   phase("expand, S, T factors, W");
-  // fp64, band 128: the fused kernel (kernels_bt.hip) applies a block to a column strip in one go, on E transposed;
-  // DLAF_MI355X_BT_FUSED=0: the two strided-batch products per wavefront (every type, every band)
-  static const bool fused_on = [] {
-    const char* e = std::getenv("DLAF_MI355X_BT_FUSED");
-    return e ? std::atoi(e) != 0 : true;
-  }();
-  const bool fused = fused_on && bt_fused_supported(b, sizeof(T), TypeInfo<T>::is_complex);
-  double *vt = nullptr, *wr = nullptr, *et = nullptr;
+  double* et = nullptr;
   const long ldet = (ncols + 63) / 64 * 64;
   if constexpr (std::is_same_v<T, double>) {
     if (fused) {
-      vt = ealloc<double>(nb2 * vblk);
-      wr = ealloc<double>(nb2 * vblk);
-      launch_bt_relayout(vx, wx, vt, wr, (long) nb2, s);
       et = ealloc<double>((size_t) ldet * n);
       launch_bt_transpose(e, lde, n, ncols, et, ldet, s);
     }
   }
-  phase("relayout + transposition");
+  phase("transposition");
   // steps of sweep group jb (its first sweep has the most)
   auto steps_of = [&](long jb) -> long {
     const long sw = jb * b;
@@ -291,8 +289,9 @@ int bt_band_to_tridiag_device(long n, int band, const T* v, long ldv, T* e, long
       const long blk = jb * nblk + ib;
       const long r0 = 1 + ib * b;
       if (fused) {
-        launch_bt_apply(vt + (size_t) blk * vblk, wr + (size_t) blk * vblk, (long) ((nblk + 2) * (long) vblk), (int) count, et, ldet,
-                        ncols, r0, (int) rows, s);
+        if constexpr (std::is_same_v<T, double>)
+          launch_bt_apply(vx + (size_t) blk * vblk, wx + (size_t) blk * vblk, (long) ((nblk + 2) * (long) vblk), (int) count, et,
+                          ldet, ncols, r0, (int) rows, s);
         return;
       }
       GemmArgs<T> g;  // W2 = V^H E
@@ -349,9 +348,8 @@ int bt_band_to_tridiag_device(long n, int band, const T* v, long ldv, T* e, long
   phase("transposition back");
   for (T* q : {vx, wx, sm, tm, taus, w2})
     DLAF_HIP_CHECK(hipFree(q));
-  for (double* q : {vt, wr, et})
-    if (q)
-      DLAF_HIP_CHECK(hipFree(q));
+  if (et)
+    DLAF_HIP_CHECK(hipFree(et));
   phase("frees");
   return 0;
 }

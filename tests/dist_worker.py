@@ -209,6 +209,9 @@ def main():
             fact.close()
         # the widenings (solver, gen_to_std, eigensolver stages): not repeated by the runs that only select another
         # issue order of the Cholesky factorization (DIST_WORKER_CHOLESKY_ONLY=1)
+        # DIST_WORKER_SKIP: sections of the widenings a run leaves to the other grids (hegst, red2band, b2t, eig)
+        skip = set(filter(None, os.environ.get("DIST_WORKER_SKIP", "").split(",")))
+        keep = lambda name, cases: [] if name in skip else cases  # noqa: E731
         if os.environ.get("DIST_WORKER_CHOLESKY_ONLY") != "1":
             # triangular solver: every side / uplo / op / diag on the reference's analytic systems
             # (test/unit/solver/test_triangular.cpp:105-141), non-zero source ranks, both communication shapes
@@ -260,8 +263,8 @@ def main():
             # generalized_to_standard on the grid: the reference's distributed test (test_gen_to_std.cpp:85-113) --
             # analytic operands, non-zero source rank, abs tolerance 10 (m+1) error, the factor untouched -- plus
             # random operands against the oracle's restatement of GenToStd::call_L
-            for t, uplo, m, mb in [("d", "L", 34, 13), ("d", "U", 34, 13), ("z", "L", 32, 5), ("z", "U", 16, 10), ("s", "L", 34, 34),
-                                   ("c", "U", 5, 8), ("d", "L", 4, 3), ("d", "L", 0, 2), ("d", "U", 200, 32), ("z", "L", 150, 32)]:
+            for t, uplo, m, mb in keep("hegst", [("d", "L", 34, 13), ("d", "U", 34, 13), ("z", "L", 32, 5), ("z", "U", 16, 10), ("s", "L", 34, 34),
+                                   ("c", "U", 5, 8), ("d", "L", 4, 3), ("d", "L", 0, 2), ("d", "U", 200, 32), ("z", "L", 150, 32)]):
                 dt = oracle.DTYPES[t]
                 sr, sc = max(0, nprow - 1), min(1, npcol - 1)
                 tmat, a, b = oracle.gen_to_std_setters(uplo, m, dt)
@@ -304,9 +307,9 @@ def main():
             # n^2 * error, the upper triangle untouched) plus fast-path sizes, a non-zero source rank, elementwise against
             # the oracle's restatement of ReductionToBand::call; then C <- Q C against the oracle (test_bt_reduction_to_band.cpp)
             from oracle import red2band as rb
-            for t, n, nb, band, src in [("d", 13, 3, 3, 0), ("d", 24, 3, 3, 1), ("d", 40, 5, 5, 0), ("z", 42, 6, 3, 1), ("d", 29, 9, 3, 0),
+            for t, n, nb, band, src in keep("red2band", [("d", 13, 3, 3, 0), ("d", 24, 3, 3, 1), ("d", 40, 5, 5, 0), ("z", 42, 6, 3, 1), ("d", 29, 9, 3, 0),
                                         ("s", 42, 12, 4, 0), ("c", 27, 9, 3, 1), ("d", 4, 4, 2, 0), ("d", 300, 64, 32, 1),
-                                        ("z", 260, 64, 32, 0), ("d", 515, 128, 64, 1), ("d", 0, 6, 2, 0)]:
+                                        ("z", 260, 64, 32, 0), ("d", 515, 128, 64, 1), ("d", 0, 6, 2, 0)]):
                 dt = oracle.DTYPES[t]
                 sr, sc = (max(0, nprow - 1), min(1, npcol - 1)) if src else (0, 0)
                 a0 = rb.random_hermitian(n, dt, seed=300 + n)
@@ -350,8 +353,8 @@ def main():
             # band_to_tridiagonal on the grid (test_band_to_tridiag.cpp:151-183: the reference's reconstruction check, a
             # non-zero source rank): every rank ends up with the whole tridiagonal matrix and reflectors, bit-identical
             from oracle import tridiag as td
-            for t, n, nb, band, src in [("d", 18, 4, 4, 1), ("z", 34, 6, 6, 0), ("d", 37, 9, 3, 1), ("c", 16, 12, 6, 0),
-                                        ("d", 300, 32, 16, 1), ("z", 260, 64, 32, 1)]:
+            for t, n, nb, band, src in keep("b2t", [("d", 18, 4, 4, 1), ("z", 34, 6, 6, 0), ("d", 37, 9, 3, 1), ("c", 16, 12, 6, 0),
+                                        ("d", 300, 32, 16, 1), ("z", 260, 64, 32, 1)]):
                 dt = oracle.DTYPES[t]
                 sr, sc = (max(0, nprow - 1), min(1, npcol - 1)) if src else (0, 0)
                 a0 = rb.random_hermitian(n, dt, seed=500 + n, banded=band)
@@ -371,8 +374,8 @@ def main():
             # hermitian_eigensolver / hermitian_generalized_eigensolver on the grid through the reference's C entries
             # (test_eigensolver.cpp, test_gen_eigensolver.cpp: testEigensolverCorrectness on the gathered results; A and the
             # eigenvector matrix with different source columns)
-            for t, n, nb, src in [("d", 34, 8, 1), ("z", 64, 16, 0), ("s", 32, 5, 1), ("d", 300, 32, 1), ("z", 260, 64, 0),
-                                  ("d", 1100, 256, 1), ("d", 5, 8, 0)]:
+            for t, n, nb, src in keep("eig", [("d", 34, 8, 1), ("z", 64, 16, 0), ("s", 32, 5, 1), ("d", 300, 32, 1), ("z", 260, 64, 0),
+                                  ("d", 1100, 256, 1), ("d", 5, 8, 0)]):
                 dt = oracle.DTYPES[t]
                 sr, sc = (max(0, nprow - 1), min(1, npcol - 1)) if src else (0, 0)
                 zsc = 0 if src else min(1, npcol - 1)
@@ -390,7 +393,7 @@ def main():
                     if not good:
                         print(f"[dist_worker] hermitian_eigensolver FAILED {t} n={n} nb={nb} grid {nprow}x{npcol}: {res}", flush=True)
                 ok &= bool(good)
-            for t, n, nb in [("d", 64, 16), ("z", 130, 32)]:
+            for t, n, nb in keep("eig", [("d", 64, 16), ("z", 130, 32)]):
                 dt = oracle.DTYPES[t]
                 sr, sc = max(0, nprow - 1), min(1, npcol - 1)
                 a0 = rb.random_hermitian(n, dt, seed=900 + n)

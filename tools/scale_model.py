@@ -42,14 +42,17 @@ class Rates:
         # measured on one MI355X (profiles/r02_final_*, profiles/r03_update_kernel_wide4_lean_ab_timing.txt)
         if nb >= 1024:
             self.r_bulk = 70.7e12           # one block per workgroup, alone (profiles/r03_update_kernel_wide4_lean_ab_timing.txt)
-            self.r_eff = 68.0e12            # whole factorization on one GPU (BENCH_r02 value)
+            self.r_eff = 69.3e12            # whole factorization on one GPU (round 3, second half: 68.7-69.8)
             self.r_trsm = 55.0e12           # trsm_rows_kernel alone (BENCH_r02 trsm_panel.achieved_TFlops)
-            self.potrf_alone, self.potrf_insitu = 0.92e-3, 3.15e-3
+            # in situ: shared compute units with raised wave priority 2.3 ms; on exclusive compute units 0.87 ms
+            # (profiles/r03_exclusive_cus_ab.txt) -- the grid order's reservation with a device-side transport
+            self.potrf_alone, self.potrf_insitu, self.potrf_excl = 0.92e-3, 2.3e-3, 0.87e-3
         else:
             self.r_bulk = (67.8e12 if cx else 62.0e12)   # z in situ 67.8 (4N^3/3 model); d nb=512 bulk 0.79 of peak
-            self.r_eff = (63.1e12 if cx else 58.8e12)    # profiles/r02_final_*: z N=32768 nb=512 63.1, C1 58.8
+            self.r_eff = (65.1e12 if cx else 60.6e12)    # round 3: z N=32768 nb=512 65.1, C1 60.6
             self.r_trsm = (30.0e12 if cx else 45.0e12)
-            self.potrf_alone, self.potrf_insitu = ((0.95e-3, 2.9e-3) if cx else (0.375e-3, 1.3e-3))
+            self.potrf_alone, self.potrf_insitu = ((0.95e-3, 2.2e-3) if cx else (0.375e-3, 0.83e-3))
+            self.potrf_excl = 0.85e-3 if cx else 0.32e-3
         self.fill = 60e-6                   # fill + drain of a bulk launch (70.7 vs 68.8 TFlop/s at 33 ms: ~0.9 ms / 15 waves)
         self.elem = 16 if cx else 8
 
@@ -92,8 +95,8 @@ def model(n, nb, pr, pc, cx, schedule, fab, reserve=32.0 / 512.0):
         bc_panel = fab.bcast(rows * tile_bytes, pc)
         bc_panel_t = fab.bcast(cols * tile_bytes, pr)
         work = (tiles * rt.flop_gemm_tile + rows * rt.flop_trsm_tile) / rt.r_eff   # (launch overheads are in R_eff)
-        if schedule == "early":
-            chain = rt.potrf_insitu + bc_diag + rt.t_trsm(1) + fab.bcast(tile_bytes, pc) + rt.t_bulk(1)
+        if schedule in ("early", "early-x"):
+            chain = (rt.potrf_excl if schedule == "early-x" else rt.potrf_insitu) + bc_diag + rt.t_trsm(1) + fab.bcast(tile_bytes, pc) + rt.t_bulk(1)
             step = max(tiles * rt.flop_gemm_tile / rt.r_eff + t_trsm, chain, bc_panel + bc_panel_t)
         else:
             chain = rt.potrf_alone + bc_diag + t_trsm + bc_panel + bc_panel_t + t_la
@@ -118,7 +121,7 @@ def main():
         print("| grid | schedule | time [ms] | TFlop/s | fraction of N x 78.6 | steps bound by the chain |")
         print("|---|---|---|---|---|---|")
         for pr, pc in ((1, 1), (1, 2), (2, 2), (2, 4)):
-            for sched in ("early", "pairs"):
+            for sched in ("early", "early-x", "pairs"):
                 t, tf, frac, cb, nt = model(n, nb, pr, pc, cx, sched, fab)
                 print(f"| {pr}x{pc} | {sched} | {t * 1e3:.0f} | {tf:.1f} | {frac:.3f} | {cb} / {nt} |")
         print()
