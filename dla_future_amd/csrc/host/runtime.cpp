@@ -738,6 +738,8 @@ void DeviceMatrix<T>::factorize_async() {
   const long sidecar_slots = [&]() -> long {
     if (const char* e = std::getenv("DLAF_MI355X_SIDECAR_SLOTS"))
       return std::atol(e);
+    if (const char* e = std::getenv("DLAF_MI355X_SIDECAR_DEFAULT"))  // another starting value, the late boost stays on
+      return std::atol(e);
     return 32;
   }();
 

@@ -75,9 +75,9 @@ SIX = pytest.mark.many_ranks
                                                pytest.param(3, 2, "R", marks=SIX), pytest.param(2, 3, "C", marks=SIX)])
 def test_distributed_cholesky_one_gpu_many_ranks(nprow, npcol, order):
     # every grid runs the factorization, the solver and the resident solves; the eigensolver stages and gen_to_std are
-    # split between the two six-rank grids (3 x 2: reduction_to_band / band_to_tridiagonal / gen_to_std, 2 x 3: the
-    # eigensolvers) -- 2 x 2 and the two-rank grids run everything
-    skip = {(3, 2): "eig", (2, 3): "red2band,b2t,hegst"}.get((nprow, npcol), "")
+    # split between the grids with four and six ranks (3 x 2: reduction_to_band / band_to_tridiagonal,
+    # 2 x 3: the eigensolvers, 2 x 2: everything but the eigensolvers) -- the two-rank grids run everything
+    skip = {(3, 2): "eig,hegst", (2, 3): "red2band,b2t,hegst", (2, 2): "eig"}.get((nprow, npcol), "")
     launch("gpu", nprow, npcol, order, timeout=600, extra_env={"DIST_WORKER_SKIP": skip})
 
 

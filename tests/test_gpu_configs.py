@@ -130,6 +130,40 @@ def test_baseline_config_on_one_gpu(dlaf, grid, oracle, t, n, nb, uplo):
 
 
 # ------------------------------------------------------------------- elementwise at the headline block size
+def test_baseline_config5_eigensolver_on_one_gpu(dlaf, grid):
+    """BASELINE configs[4] at its stated size on one GPU: fp64 symmetric eigensolver N = 20480, nb = 512 (band 128: every
+    stage on its fast path, the fused back-transformation included) through the reference's C entry.  Checked by
+    size-independent properties: eigenvalues sorted, sum(w) = trace(A) and sum(w^2) = ||A||_F^2 (invariants of the
+    similarity transformations), residual and orthogonality of a sample of eigenpairs within the bars of the
+    reference's testEigensolverCorrectness (test_eigensolver.cpp: 2 n eps |w|max, 10 n eps)."""
+    n, nb = 20480, 512
+    rng = np.random.default_rng(20480)
+    a0 = np.empty((n, n), dtype=np.float64, order="F")
+    for j0 in range(0, n, 2048):
+        a0[:, j0:j0 + 2048] = rng.uniform(-1, 1, (n, min(2048, n - j0)))
+    low = np.tril(a0)                      # the lower triangle is the matrix
+    tr = float(np.trace(low))
+    fro2 = float(2.0 * np.sum(low * low) - np.sum(np.diag(low) ** 2))
+    a = a0.copy(order="F")
+    a[np.triu_indices(n, 1)] = -9.9        # must not be read
+    w, z = dlaf.hermitian_eigensolver(grid, "L", a, nb)
+    del a
+    eps = np.finfo(np.float64).eps
+    assert np.all(np.diff(w) >= 0)
+    wmax = float(np.abs(w).max())
+    assert abs(float(np.sum(w)) - tr) <= 10 * n * eps * wmax * np.sqrt(n)
+    assert abs(float(np.sum(w * w)) - fro2) <= 100 * n * eps * fro2
+    cols = np.unique(np.concatenate([np.arange(0, n, n // 16), [n - 1]]))
+    zc = z[:, cols]
+    az = low @ zc + np.tril(a0, -1).T @ zc
+    assert np.abs(az - zc * w[cols][None, :]).max() <= 2 * n * 2 * eps * wmax
+    assert np.abs(zc.T @ zc - np.eye(len(cols))).max() <= 10 * n * 2 * eps
+    # orthogonality against a second sample (different columns)
+    other = z[:, cols[:-1] + 1]
+    assert np.abs(zc.T @ other).max() <= 10 * n * 2 * eps
+    assert all(ms > 0 for ms in dlaf.eigensolver_profile())
+
+
 @pytest.mark.parametrize("t,uplo,n", [("d", "L", 2048), ("d", "U", 2048), ("z", "L", 2048), ("z", "U", 2048),
                                       ("d", "L", 3072 + 17), ("z", "U", 3072 + 17)])
 def test_elementwise_vs_oracle_at_nb1024(dlaf, grid, oracle, t, uplo, n):
