@@ -431,3 +431,18 @@ def test_gen_to_std_oracle_matches_lapack_hegst(oracle):
             assert np.abs(oracle.tri(uplo, ref) - oracle.tri(uplo, got)).max() < 50 * n * oracle.eps_of(dt)
             other = np.triu(got, 1) if uplo == "L" else np.tril(got, -1)
             assert np.array_equal(other, np.triu(a0, 1) if uplo == "L" else np.tril(a0, -1))
+
+
+def test_rectangular_block_scatter_gather_round_trip():
+    """scatter_rect / gather_rect (MB x NB blocks, matrix.h block size != square -- the right-hand sides of the solver
+    tests): the square-block case equals scatter(), every case round-trips, every element lands exactly once."""
+    from oracle import oracle
+    a = np.arange(19 * 25, dtype=np.float64).reshape(19, 25)
+    for pr, pc, sr, sc in [(1, 1, 0, 0), (2, 3, 1, 1), (3, 2, 2, 0), (1, 3, 0, 2)]:
+        for mb, nb in [(6, 5), (3, 9), (5, 5), (19, 1)]:
+            locs = oracle.scatter_rect(a, mb, nb, pr, pc, sr, sc, extra_ld=2)
+            assert sum(v.size for v in locs.values()) == a.size
+            assert np.array_equal(oracle.gather_rect(locs, 19, 25, mb, nb, pr, pc, sr, sc), a)
+        sq = oracle.scatter(a, 5, pr, pc, sr, sc)
+        rc = oracle.scatter_rect(a, 5, 5, pr, pc, sr, sc)
+        assert all(np.array_equal(sq[k], rc[k]) for k in sq)
