@@ -117,6 +117,13 @@ __device__ __forceinline__ int acc_as_operand_k(int g, int v) {
   return Mma<R>::irow(g, v);
 }
 
+// Physical placement of the calling wave: XCD (HW_REG_XCC_ID[3:0]) and shader engine / array / compute unit
+// (HW_REG_HW_ID[15:8]).  Performance tool only: nothing depends on it for correctness.
+__device__ __forceinline__ unsigned phys_cu_key(unsigned& xcc) {
+  xcc = (unsigned) __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
+  return (unsigned) __builtin_amdgcn_s_getreg((7 << 11) | (8 << 6) | 4) & 0xffu;
+}
+
 constexpr int kThreads = 256;  // 4 waves per workgroup (the default; BlockCfg::THREADS says otherwise where it differs)
 constexpr int kLdsPad = 16;    // elements of padding per k-row of an LDS panel image:
                                // (ROWS+16)*8 B = 128 mod 256 and (ROWS+16)*4 B = 64 mod 128,

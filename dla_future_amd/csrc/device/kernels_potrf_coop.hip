@@ -253,9 +253,8 @@ __device__ __forceinline__ void coop_mma64_rega(const real_t<T> (&a_re)[16], con
 }
 
 template <class T>
-__global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__ tile, int ld, int kb,
-                                                                  T* __restrict__ winv, int* info, int info_base,
-                                                                  unsigned* sync, long spin_limit, int prio) {
+__device__ __forceinline__ void potrf_coop_body(T* __restrict__ tile, int ld, int kb, T* __restrict__ winv, int* info,
+                                                int info_base, unsigned* sync, long spin_limit, int prio) {
   using C = CoopCfg<T>;
   using R = real_t<T>;
   using acc_t = typename Mma<R>::acc_t;
@@ -627,6 +626,24 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
   }
 }
 
+// The strip counts itself in cu_busy[XCD][compute unit] while it runs: a persistent bulk-update workgroup on the same
+// compute unit sits out between two work items until the strip has left (kernels_update.hip).
+template <class T>
+__global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__ tile, int ld, int kb,
+                                                                  T* __restrict__ winv, int* info, int info_base,
+                                                                  unsigned* sync, long spin_limit, int prio, int* cu_busy) {
+  int* mine = nullptr;
+  if (cu_busy != nullptr && threadIdx.x == 0) {
+    unsigned xcc;
+    const unsigned key = phys_cu_key(xcc);
+    mine = cu_busy + (xcc * 256u + key);
+    atomicAdd(mine, 1);
+  }
+  potrf_coop_body<T>(tile, ld, kb, winv, info, info_base, sync, spin_limit, prio);
+  if (mine != nullptr)
+    atomicSub(mine, 1);
+}
+
 // DLAF_MI355X_POTRF_PRIO=0 leaves the strips at the default wave priority (A/B runs)
 static int coop_wave_prio() {
   static const int p = [] {
@@ -635,6 +652,8 @@ static int coop_wave_prio() {
   }();
   return p;
 }
+
+int* cu_busy_table();  // kernels_update.hip
 
 static void fatal_device_config(const char* what) {
   std::fprintf(stderr, "[dlaf_mi355x] %s\n", what);
@@ -654,7 +673,7 @@ void launch_potrf_coop(T* tile, int ld, int kb, T* winv, int* info, int info_bas
   if (!sync_is_zero)
     (void) hipMemsetAsync(sync, 0, sizeof(unsigned) * ((size_t) G + (size_t) G * G), stream);
   hipLaunchKernelGGL((potrf_coop_kernel<T>), dim3((unsigned) G), dim3(kThreads), CoopCfg<T>::LDS_BYTES, stream, tile, ld,
-                     kb, winv, info, info_base, sync, coop_spin_limit(), coop_wave_prio());
+                     kb, winv, info, info_base, sync, coop_spin_limit(), coop_wave_prio(), cu_busy_table());
 }
 
 template <class T>

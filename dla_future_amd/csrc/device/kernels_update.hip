@@ -88,14 +88,9 @@ struct UpdateMap {
                        // XCD (g_cu_rank) leave at once -- whole compute units stay free for the kernels beside the update
   unsigned excl_budget;  // ... but no more than this many per launch (counters[15] counts them)
   int steal;           // persist: a workgroup whose queue is empty drains the other queues
+  int* cu_busy;        // persist: per (XCD, compute unit) count of tile-POTRF strips resident there (null: off) -- a bulk
+                       // workgroup that shares its compute unit with a strip pauses between two work items
 };
-
-// Physical placement of the calling wave: XCD (HW_REG_XCC_ID[3:0]) and shader engine / array / compute unit
-// (HW_REG_HW_ID[15:8]).  Performance tool only: nothing depends on it for correctness.
-__device__ __forceinline__ unsigned phys_cu_key(unsigned& xcc) {
-  xcc = (unsigned) __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
-  return (unsigned) __builtin_amdgcn_s_getreg((7 << 11) | (8 << 6) | 4) & 0xffu;
-}
 
 // rank of a compute unit among the compute units of its XCD that the probe launch of update_kernels_init() saw
 // (255: not seen).  "The first r compute units of every XCD" is the set a persistent bulk launch vacates.
@@ -495,8 +490,23 @@ __global__ __launch_bounds__(UpdateCfg<T>::type::THREADS, UpdateCfg<T>::min_wave
   __shared__ int next_s0;
   const int nslab = p.K / UpdateCfg<T>::type::BK;
   int q = q0, tried = 1;
+  // The tile POTRF is a latency chain of a few waves; on a compute unit it shares with a bulk workgroup it runs 2.5 x
+  // slower than alone (issue slots, LDS, the texture path), on one of its own at its stand-alone speed.  So a bulk
+  // workgroup whose compute unit holds a POTRF strip (the strips count themselves in cu_busy) sits out between two
+  // work items until the strip has left: 16 of 480 workgroups for a millisecond per diagonal tile.  Bounded.
+  int* my_busy = nullptr;
+  if (mp.cu_busy != nullptr && threadIdx.x == 0) {
+    unsigned xcc;
+    const unsigned key = phys_cu_key(xcc);
+    my_busy = mp.cu_busy + (xcc * 256u + key);
+  }
   for (;;) {
     if (threadIdx.x == 0) {
+      if (my_busy != nullptr) {
+        int spins = 0;
+        while (__hip_atomic_load(my_busy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0 && ++spins < 4000)
+          __builtin_amdgcn_s_sleep(64);
+      }
       next_item = atomicAdd(&mp.counters[q], 1u);
       next_s0 = (mp.kphase_ticks != 0 && nslab > 1) ? (int) ((wall_clock64() / mp.kphase_ticks) % (unsigned) nslab) : 0;
     }
@@ -582,6 +592,24 @@ static unsigned kphase_ticks(int resident) {
 template <class T>
 static bool aligned16(const void* ptr, long stride_elems) {
   return (reinterpret_cast<uintptr_t>(ptr) % 16 == 0) && ((stride_elems * (long) sizeof(T)) % 16 == 0);
+}
+
+// table of resident tile-POTRF strips per (XCD, compute unit): 8 x 256 counters, shared with kernels_potrf_coop.hip
+// through cu_busy_table() (null: the pause is off, DLAF_MI355X_POTRF_YIELD=0)
+static int* g_cu_busy = nullptr;
+int* cu_busy_table() {
+  static const bool on = [] {
+    const char* e = std::getenv("DLAF_MI355X_POTRF_YIELD");
+    return e ? std::atoi(e) != 0 : true;
+  }();
+  if (on && g_cu_busy == nullptr) {
+    if (hipMalloc(reinterpret_cast<void**>(&g_cu_busy), 8 * 256 * sizeof(int)) != hipSuccess ||
+        hipMemset(g_cu_busy, 0, 8 * 256 * sizeof(int)) != hipSuccess) {
+      (void) hipGetLastError();
+      g_cu_busy = nullptr;
+    }
+  }
+  return g_cu_busy;
 }
 
 // what the probe launch of update_kernels_init() found: XCDs and compute units per XCD (0: no probe, no exclusive mode)
@@ -676,6 +704,7 @@ void launch_update(const UpdateArgs<T>& a, hipStream_t stream, int role, long ma
     mp.lockstep = update_lockstep() ? 1 : 0;
     mp.kphase_ticks = kphase_ticks<T>((int) (grid));
     mp.steal = (update_steal() && !mp.lockstep) ? 1 : 0;
+    mp.cu_busy = (role == 0) ? g_cu_busy : nullptr;
     if (excl_rank > 0) {
       mp.excl_rank = (int) excl_rank;
       mp.excl_budget = (unsigned) excl_slots;
@@ -830,6 +859,7 @@ void update_kernels_init() {
   update_init_one<cfloat>();
   update_init_one<cdouble>();
   probe_compute_units();
+  (void) cu_busy_table();
 }
 
 template void launch_update<float>(const UpdateArgs<float>&, hipStream_t, int, long, unsigned*, bool, long);

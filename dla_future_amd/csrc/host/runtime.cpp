@@ -985,13 +985,10 @@ void DeviceMatrix<T>::factorize_async() {
     return (dist && tr->device_side()) ? 32 : 0;
   }();
 
-  // early-diagonal order: what the bulk leaves to the tile POTRF and the transport's kernels.  With a device-side
-  // transport the sum is rounded up to a whole round over the shader engines (64 slots), so that the reservation is
-  // made as exclusive compute units (see `update` above): a step of a multi-GPU run is bound by the chain POTRF ->
-  // bcast -> TRSM -> bcast, and the POTRF on compute units of its own takes 0.9 instead of 2.3 ms (z nb = 512: 0.85
-  // instead of 2.2) for 16 more slots (3 % of the bulk) at nb = 512 and none at nb = 1024.
-  const long grid_reserve = (comm_slots > 0 && potrf_slots + comm_slots > 0) ? ((potrf_slots + comm_slots + 63) / 64) * 64
-                                                                               : potrf_slots + comm_slots;
+  // early-diagonal order: what the bulk leaves to the tile POTRF and the transport's kernels (a whole round over the
+  // shader engines -- 64 slots: nb = 1024 with a device-side transport -- is made as exclusive compute units, see
+  // `update` above; otherwise the strips share compute units and the bulk workgroups beside them sit out)
+  const long grid_reserve = potrf_slots + comm_slots;
 
   Step prev;  // step k-1, whose bulk update is still to be issued (in part or in full)
 

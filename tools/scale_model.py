@@ -44,14 +44,15 @@ class Rates:
             self.r_bulk = 70.7e12           # one block per workgroup, alone (profiles/r03_update_kernel_wide4_lean_ab_timing.txt)
             self.r_eff = 69.3e12            # whole factorization on one GPU (round 3, second half: 68.7-69.8)
             self.r_trsm = 55.0e12           # trsm_rows_kernel alone (BENCH_r02 trsm_panel.achieved_TFlops)
-            # in situ: shared compute units with raised wave priority 2.3 ms; on exclusive compute units 0.87 ms
+            # in situ: shared compute units with the neighbouring bulk workgroups sitting out 1.0 ms (2.15 ms with
+            # raised wave priority alone; profiles/r03_potrf_yield_ab.txt); on exclusive compute units 0.87 ms
             # (profiles/r03_exclusive_cus_ab.txt) -- the grid order's reservation with a device-side transport
-            self.potrf_alone, self.potrf_insitu, self.potrf_excl = 0.92e-3, 2.3e-3, 0.87e-3
+            self.potrf_alone, self.potrf_insitu, self.potrf_excl = 0.92e-3, 1.0e-3, 0.87e-3
         else:
             self.r_bulk = (67.8e12 if cx else 62.0e12)   # z in situ 67.8 (4N^3/3 model); d nb=512 bulk 0.79 of peak
             self.r_eff = (65.1e12 if cx else 60.6e12)    # round 3: z N=32768 nb=512 65.1, C1 60.6
             self.r_trsm = (30.0e12 if cx else 45.0e12)
-            self.potrf_alone, self.potrf_insitu = ((0.95e-3, 2.2e-3) if cx else (0.375e-3, 0.83e-3))
+            self.potrf_alone, self.potrf_insitu = ((0.95e-3, 0.94e-3) if cx else (0.375e-3, 0.37e-3))
             self.potrf_excl = 0.85e-3 if cx else 0.32e-3
         self.fill = 60e-6                   # fill + drain of a bulk launch (70.7 vs 68.8 TFlop/s at 33 ms: ~0.9 ms / 15 waves)
         self.elem = 16 if cx else 8
