@@ -60,6 +60,12 @@ def main():
     grid, rank_of = make_grid(dlaf, nprow, npcol, order)
     rank = dist.get_rank()
     ok = True
+
+    def said(cond, what):
+        """a check that would otherwise fail without a word: say which one (every rank, once)"""
+        if not cond:
+            print(f"[dist_worker] rank {rank}: FAILED {what}", flush=True)
+        return bool(cond)
     if mode == "cpu":
         # 1. broadcast callback wiring through the C ABI: row then column communicator
         for axis, nroots in ((0, npcol), (1, nprow)):
@@ -71,18 +77,18 @@ def main():
                 r = dlaf.lib().dlaf_mi355x_grid_host_bcast(grid.context, axis, root, buf.ctypes.data, buf.nbytes)
                 assert r == 0
                 expect = 1000 * axis + 100 * root + (grid.myrow if axis == 0 else grid.mycol)
-                ok &= bool((buf == expect).all())
+                ok &= said(bool((buf == expect).all()), "bool((buf == expect).all()) (line 80)")
         # 2. every rank generates its block-cyclic share; the assembled matrix is the oracle's
         for (n, nb, sr, sc) in [(45, 8, 0, 0), (34, 13, nprow - 1, min(1, npcol - 1))]:
             rows, cols = grid.local_shape(n, nb, sr, sc)
             loc = np.zeros((max(1, rows), max(1, cols)), order="F")[:rows, :cols]
             dlaf.set_random_hermitian_positive_definite(grid, loc, n, nb, sr, sc)
             full = gather_global(loc, grid, n, nb, sr, sc, oracle)
-            ok &= bool(np.array_equal(full, oracle.set_random_hpd(n, nb, np.float64)))
+            ok &= said(bool(np.array_equal(full, oracle.set_random_hpd(n, nb, np.float64))), "bool(np.array_equal(full, oracle.set_random_hpd(n, nb, np.float64))) (line 87)")
         grid.barrier()
     else:
         dlaf.initialize()
-        ok &= grid.selftest(3 << 14) == 0   # row / column communicator wiring through the Transport interface
+        ok &= said(grid.selftest(3 << 14) == 0, "grid.selftest(3 << 14) == 0 (line 91)")  # row / column communicator wiring through the Transport interface
         cases = [("d", "L", 150, 32), ("d", "U", 150, 32), ("z", "L", 100, 16), ("z", "U", 70, 16),
                  ("s", "L", 96, 32), ("c", "U", 64, 16), ("d", "L", 34, 13), ("d", "L", 5, 8), ("d", "U", 260, 64),
                  ("d", "L", 530, 32), ("z", "U", 300, 16), ("d", "U", 1100, 128), ("z", "L", 700, 128)]
@@ -95,7 +101,7 @@ def main():
             dlaf.set_random_hermitian_positive_definite(grid, loc, n, nb, sr, sc)
             a0 = gather_global(loc, grid, n, nb, sr, sc, oracle)
             info = dlaf.cholesky_factorization(grid, uplo, loc, nb, sr, sc, n=n)
-            ok &= info == 0
+            ok &= said(info == 0, "info == 0 (line 104)")
             got = gather_global(loc, grid, n, nb, sr, sc, oracle)
             if rank == 0:
                 ref = a0.copy(order="F")
@@ -109,7 +115,7 @@ def main():
                 if not good:
                     print(f"[dist_worker] FAILED case {t}{uplo} n={n} nb={nb} grid {nprow}x{npcol}: max diff {md}", flush=True)
                 ok &= good
-            ok &= bool((store[rows:, :] == 7.5).all())
+            ok &= said(bool((store[rows:, :] == 7.5).all()), "bool((store[rows:, :] == 7.5).all()) (line 118)")
         # Communication pattern (recording transport): every member of a row / column communicator logs the SAME
         # sequence of broadcasts for it -- the reference's communicator-pipeline property
         # (sender/transform_mpi.h:60-75) -- under both issue orders a grid can run, and the transposed panel
@@ -126,7 +132,7 @@ def main():
                 info = dlaf.cholesky_factorization(grid, uplo, loc, nb, sr, sc, n=n)
                 ev = grid.comm_log_events()
                 grid.comm_log(False)
-                ok &= info == 0
+                ok &= said(info == 0, "info == 0 (line 135)")
                 allev = [None] * dist.get_world_size()
                 dist.all_gather_object(allev, (grid.myrow, grid.mycol, ev))
                 if rank == 0:
@@ -180,7 +186,7 @@ def main():
             # device-resident entry: same contract
             m = dlaf.DeviceMatrix(grid, dt, uplo, n, nb, sr, sc)
             m.upload(np.asfortranarray(oracle.scatter(a0, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)]))
-            ok &= m.factorize() == bad + 1
+            ok &= said(m.factorize() == bad + 1, "m.factorize() == bad + 1 (line 189)")
             m.close()
         # device-side residual checker with the MAX reduction over the grid (miniapp check_cholesky)
         for t, uplo, n, nb in [("d", "L", 200, 32), ("z", "U", 90, 16)]:
@@ -194,7 +200,7 @@ def main():
             fact = dlaf.DeviceMatrix(grid, dt, uplo, n, nb, sr, sc)
             orig.upload(loc)
             fact.copy_from(orig)
-            ok &= fact.factorize() == 0
+            ok &= said(fact.factorize() == 0, "fact.factorize() == 0 (line 203)")
             fact.download(loc)
             got = gather_global(loc, grid, n, nb, sr, sc, oracle)
             diff, norm_a = orig.residual_against(fact)
@@ -271,9 +277,9 @@ def main():
                 la = np.asfortranarray(oracle.scatter(a, mb, nprow, npcol, sr, sc, extra_ld=1)[(grid.myrow, grid.mycol)])
                 lt = np.asfortranarray(oracle.scatter(tmat, mb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
                 lt0 = lt.copy(order="F")
-                ok &= dlaf.generalized_to_standard(grid, uplo, la, lt, mb, sr, sc, n=m) == 0
+                ok &= said(dlaf.generalized_to_standard(grid, uplo, la, lt, mb, sr, sc, n=m) == 0, "dlaf.generalized_to_standard(grid, uplo, la, lt, mb, sr, sc, n=m) == 0 (line 280)")
                 got = gather_global(la, grid, m, mb, sr, sc, oracle)
-                ok &= bool(np.array_equal(lt, lt0))
+                ok &= said(bool(np.array_equal(lt, lt0)), "bool(np.array_equal(lt, lt0)) (line 282)")
                 if rank == 0:
                     err = (8 if t in "cz" else 2) * oracle.eps_of(dt)
                     good, md = oracle.check_near(b, got, 0, 10 * (m + 1) * err)
@@ -289,7 +295,7 @@ def main():
                 assert oracle.cholesky_local(uplo, fac, nb) == 0
                 la = np.asfortranarray(oracle.scatter(a0, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
                 lf = np.asfortranarray(oracle.scatter(fac, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
-                ok &= dlaf.generalized_to_standard(grid, uplo, la, lf, nb, sr, sc, n=n) == 0
+                ok &= said(dlaf.generalized_to_standard(grid, uplo, la, lf, nb, sr, sc, n=n) == 0, "dlaf.generalized_to_standard(grid, uplo, la, lf, nb, sr, sc, n=n) == 0 (line 298)")
                 got = gather_global(la, grid, n, nb, sr, sc, oracle)
                 if rank == 0:
                     ref = a0.copy(order="F")
@@ -429,7 +435,7 @@ def main():
                 am.upload(la)
                 bm = dlaf.GeneralDeviceMatrix(grid, dt, n, nrhs, nb, sr, sc)
                 bm.upload(lb)
-                ok &= am.factorize() == 0
+                ok &= said(am.factorize() == 0, "am.factorize() == 0 (line 438)")
                 dlaf.potrs_device(uplo, am, bm)
                 bm.download(lb)
                 got = gather_global(lb, grid, nrhs, nb, sr, sc, oracle, m=n)
@@ -447,11 +453,11 @@ def main():
         loc = np.asfortranarray(locs[(grid.myrow, grid.mycol)])
         lld = max(1, loc.shape[0])
         info = dlaf.pxpotrf("L", n, loc, 1, 1, [1, grid.context, n, n, nb, nb, 0, 0, lld])
-        ok &= info == 0
+        ok &= said(info == 0, "info == 0 (line 456)")
         got = gather_global(loc, grid, n, nb, 0, 0, oracle)
         tol = 4 * (n + 1) * 2 * np.finfo(np.float64).eps
         good, md = oracle.check_near(l, got, tol, tol)
-        ok &= good
+        ok &= said(good, f"p?potrf known answer: max diff {md}")
         grid.barrier()
     flags = [None] * dist.get_world_size()
     dist.all_gather_object(flags, bool(ok))
