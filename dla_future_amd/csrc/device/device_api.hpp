@@ -154,6 +154,9 @@ struct LayoutArgs {
   T alpha{};
   // restrict the move to view tile columns [jl_first, jl_first + jl_count) (jl_count 0: to the last one)
   int jl_first = 0, jl_count = 0;
+  // view row r / column c takes source view row rows-1-r / column cols-1-c (the solver turns a backward sweep over an
+  // upper triangular matrix into the forward sweep of its reversal)
+  int rev_rows = 0, rev_cols = 0;
 };
 template <class T>
 void launch_to_tiles(const LayoutArgs<T>& args, hipStream_t stream);

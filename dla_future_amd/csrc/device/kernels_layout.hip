@@ -48,13 +48,16 @@ __global__ __launch_bounds__(kThreads) void layout_kernel(LayoutArgs<T> p, int s
     return;
   T* tile = p.tiles + ((long) il + (long) jl * p.ltr) * p.nb * p.nb;
   const int tx = threadIdx.x % kLT, ty = threadIdx.x / kLT;  // 32 x 8
+  // source position of view element (row, col): reversed axes count from the far end
+  auto srow = [&](long vr) { return p.rev_rows ? p.rows - 1 - vr : vr; };
+  auto scol = [&](long vc) { return p.rev_cols ? p.cols - 1 - vc : vc; };
 
   if (!p.transpose) {
     for (int cc = ty; cc < kLT; cc += kThreads / kLT) {
       const int r = r0 + tx, c = c0 + cc;
       if (r < rows_tile && c < cols_tile) {
         T* td = tile + r + (long) c * p.nb;
-        T* cd = p.cm + (vrow0 + r) + (vcol0 + c) * p.ld_cm;
+        T* cd = p.cm + srow(vrow0 + r) + scol(vcol0 + c) * p.ld_cm;
         if (TO_TILES)
           *td = xf(*cd);
         else if (!diag || r >= c)
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(kThreads) void layout_kernel(LayoutArgs<T> p, int s
       for (int rr = ty; rr < kLT; rr += kThreads / kLT) {
         const int r = r0 + rr, c = c0 + tx;
         if (r < rows_tile && c < cols_tile)
-          buf[rr][tx] = xf(p.cm[(vcol0 + c) + (vrow0 + r) * p.ld_cm]);
+          buf[rr][tx] = xf(p.cm[scol(vcol0 + c) + srow(vrow0 + r) * p.ld_cm]);
       }
       __syncthreads();
       for (int cc = ty; cc < kLT; cc += kThreads / kLT) {
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(kThreads) void layout_kernel(LayoutArgs<T> p, int s
       for (int rr = ty; rr < kLT; rr += kThreads / kLT) {
         const int r = r0 + rr, c = c0 + tx;
         if (r < rows_tile && c < cols_tile && (!diag || r >= c))
-          p.cm[(vcol0 + c) + (vrow0 + r) * p.ld_cm] = buf[rr][tx];
+          p.cm[scol(vcol0 + c) + srow(vrow0 + r) * p.ld_cm] = buf[rr][tx];
       }
     }
   }

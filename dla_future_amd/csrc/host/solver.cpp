@@ -466,11 +466,24 @@ int triangular_solver_host(Grid* g, char side, char uplo, char op, char diag, T 
     if (nb_free <= 0)
       nb_free = nb;
     Bd.create_rhs(g, left, m, n, left ? nb : nb_free, left ? nb_free : nb, b_isrc, b_jsrc);
+    // One process, whole tiles: an upper triangular T (swept backward by the round-1 strips kernel) is laid out
+    // REVERSED -- T'(i, j) = T(na-1-i, na-1-j) is lower triangular, X'(:, j) = X(:, na-1-j) solves X' T'^H = B' -- and
+    // the forward sweep of the row-owner kernel does the work; the download reverses back.
+    // DLAF_MI355X_SOLVER_REVERSE=0: the backward sweep (A/B).
+    static const bool reverse_on = [] {
+      const char* e = std::getenv("DLAF_MI355X_SOLVER_REVERSE");
+      return e ? std::atoi(e) != 0 : true;
+    }();
+    const bool reversed = reverse_on && t_upper && g->nranks == 1 && na % nb == 0;
+    if (reversed) {
+      Td.rev_rows = Td.rev_cols = true;
+      Bd.rev_cols = true;  // the view's columns are the triangular dimension
+    }
     Td.upload(a, lda, t_conj, false, T{}, s);
     // Left: B_dev = (alpha B)^H = conj(alpha) B^H (the relayout conjugates first, then scales)
     Bd.upload(b, ldb, left, true, left ? conj_el(alpha) : alpha, s);
     DLAF_HIP_CHECK(hipStreamSynchronize(s));
-    solve_canonical(Td, Bd, t_upper, unit);
+    solve_canonical(Td, Bd, reversed ? false : t_upper, unit);
     Bd.download(b, ldb, left, s);
     DLAF_HIP_CHECK(hipStreamSynchronize(s));
   }

@@ -31,6 +31,9 @@ struct TileMatrix {
   // rows.P / rows.rank / rows.n unless the row axis has been localized (create_rhs).
   int row_P = 1, row_rank = 0;
   long rows_global = 0;
+  // upload / download take the view's rows / columns from the far end (one process, whole tiles only: the ragged
+  // tile must stay the last one)
+  bool rev_rows = false, rev_cols = false;
 
   // m_src x n_src: global size of the caller's matrix, (isrc, jsrc) its source process
   void create(Grid* g, bool transposed_, long m_src, long n_src, int nb_, int isrc, int jsrc, T* borrow = nullptr) {
@@ -101,6 +104,8 @@ struct TileMatrix {
     a.ci = cols.shift();
     a.transpose = transposed ? 1 : 0;
     a.full = 1;
+    a.rev_rows = rev_rows ? 1 : 0;
+    a.rev_cols = rev_cols ? 1 : 0;
     return a;
   }
   void source_extents(long& srows, long& scols) const {
