@@ -122,7 +122,8 @@ void launch_invert_diag_blocks(const T* tile, int ld, int kb, T* winv, int* info
 // potrf_coop_sync_words(kb).
 template <class T>
 void launch_potrf_coop(T* tile, int ld, int kb, T* winv, int* info, int info_base, unsigned* sync,
-                       hipStream_t stream, bool sync_is_zero = false);
+                       hipStream_t stream, bool sync_is_zero = false, bool count_strips = true);
+// count_strips: the strips register in the per-compute-unit table the bulk update kernel consults (the POTRF yield)
 inline size_t potrf_coop_sync_words(int kb) {
   const size_t g = (size_t) ((kb + kDiagBlock - 1) / kDiagBlock);
   return g + g * g;

@@ -662,7 +662,7 @@ static void fatal_device_config(const char* what) {
 
 template <class T>
 void launch_potrf_coop(T* tile, int ld, int kb, T* winv, int* info, int info_base, unsigned* sync,
-                       hipStream_t stream, bool sync_is_zero) {
+                       hipStream_t stream, bool sync_is_zero, bool count_strips) {
   if (kb <= 0)
     return;
   const int G = (kb + kCB - 1) / kCB;
@@ -673,7 +673,7 @@ void launch_potrf_coop(T* tile, int ld, int kb, T* winv, int* info, int info_bas
   if (!sync_is_zero)
     (void) hipMemsetAsync(sync, 0, sizeof(unsigned) * ((size_t) G + (size_t) G * G), stream);
   hipLaunchKernelGGL((potrf_coop_kernel<T>), dim3((unsigned) G), dim3(kThreads), CoopCfg<T>::LDS_BYTES, stream, tile, ld,
-                     kb, winv, info, info_base, sync, coop_spin_limit(), coop_wave_prio(), cu_busy_table());
+                     kb, winv, info, info_base, sync, coop_spin_limit(), coop_wave_prio(), count_strips ? cu_busy_table() : nullptr);
 }
 
 template <class T>
@@ -689,9 +689,9 @@ void potrf_coop_kernels_init() {
   coop_init_one<cdouble>();
 }
 
-template void launch_potrf_coop<float>(float*, int, int, float*, int*, int, unsigned*, hipStream_t, bool);
-template void launch_potrf_coop<double>(double*, int, int, double*, int*, int, unsigned*, hipStream_t, bool);
-template void launch_potrf_coop<cfloat>(cfloat*, int, int, cfloat*, int*, int, unsigned*, hipStream_t, bool);
-template void launch_potrf_coop<cdouble>(cdouble*, int, int, cdouble*, int*, int, unsigned*, hipStream_t, bool);
+template void launch_potrf_coop<float>(float*, int, int, float*, int*, int, unsigned*, hipStream_t, bool, bool);
+template void launch_potrf_coop<double>(double*, int, int, double*, int*, int, unsigned*, hipStream_t, bool, bool);
+template void launch_potrf_coop<cfloat>(cfloat*, int, int, cfloat*, int*, int, unsigned*, hipStream_t, bool, bool);
+template void launch_potrf_coop<cdouble>(cdouble*, int, int, cdouble*, int*, int, unsigned*, hipStream_t, bool, bool);
 
 }  // namespace dlaf_mi355x

@@ -562,12 +562,12 @@ static bool potrf_use_chain() {
 
 template <class T>
 static void potrf_tile(T* t, int ld, int kb, T* winv, int* info, int info_base, unsigned* sync, hipStream_t s,
-                       bool sync_is_zero = false) {
+                       bool sync_is_zero = false, bool count_strips = true) {
   constexpr int JB = kDiagBlock;
   if (!potrf_use_chain()) {
     // one resident cooperative launch (kernels_potrf_coop.hip); DLAF_MI355X_POTRF=chain selects the
     // multi-launch form below (diagonal block kernel + TRSM kernel + update kernel per 64 columns)
-    launch_potrf_coop(t, ld, kb, winv, info, info_base, sync, s, sync_is_zero);
+    launch_potrf_coop(t, ld, kb, winv, info, info_base, sync, s, sync_is_zero, count_strips);
     return;
   }
   for (int j0 = 0; j0 < kb; j0 += JB) {
@@ -926,7 +926,10 @@ void DeviceMatrix<T>::factorize_async() {
     const double cxf = TypeInfo<T>::is_complex ? 4.0 : 1.0;
     prof_begin(3, s_panel);
     potrf_tile(tile(rows.local_of(k), cols.local_of(k)), nb, kb, winv_of(k), info, (int) (k * nb),
-               coop_sync + 16 * coop_sync_update_slices + coop_sync_potrf_words * (size_t) k, s_panel, sync_pool);
+               coop_sync + 16 * coop_sync_update_slices + coop_sync_potrf_words * (size_t) k, s_panel, sync_pool,
+               /* the POTRF yield: one process only -- measured there; on process grids the strips
+                  stay out of the table */
+               !dist);
     prof_end(3, s_panel, cxf * (double) kb * kb * kb / 3.0, (double) kb * kb * sizeof(T));
   };
 

@@ -186,7 +186,8 @@ def main():
             # device-resident entry: same contract
             m = dlaf.DeviceMatrix(grid, dt, uplo, n, nb, sr, sc)
             m.upload(np.asfortranarray(oracle.scatter(a0, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)]))
-            ok &= said(m.factorize() == bad + 1, "m.factorize() == bad + 1 (line 189)")
+            r_info = m.factorize()
+            ok &= said(r_info == bad + 1, f"resident non-SPD {t}{uplo} n={n} nb={nb}: factorize() returned {r_info}, expected {bad + 1}")
             m.close()
         # device-side residual checker with the MAX reduction over the grid (miniapp check_cholesky)
         for t, uplo, n, nb in [("d", "L", 200, 32), ("z", "U", 90, 16)]:
