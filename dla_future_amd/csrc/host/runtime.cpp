@@ -915,6 +915,11 @@ void DeviceMatrix<T>::factorize_async() {
     prof_end(2, ts, fl, by);
   };
 
+  static const bool yield_on_grids = [] {
+    const char* e = std::getenv("DLAF_MI355X_POTRF_YIELD_GRIDS");
+    return e && std::atoi(e) != 0;
+  }();
+
   // diagonal tile k on its owner (s_panel); the inverted diagonal blocks alternate between two buffers
   // because POTRF(k+1) may run while TRSM(k) still reads those of step k
   auto winv_of = [&](long k) { return winv + (size_t) (k & 1) * winv_elems(); };
@@ -928,8 +933,9 @@ void DeviceMatrix<T>::factorize_async() {
     potrf_tile(tile(rows.local_of(k), cols.local_of(k)), nb, kb, winv_of(k), info, (int) (k * nb),
                coop_sync + 16 * coop_sync_update_slices + coop_sync_potrf_words * (size_t) k, s_panel, sync_pool,
                /* the POTRF yield: one process only -- measured there; on process grids the strips
-                  stay out of the table */
-               !dist);
+                  stay out of the table (DLAF_MI355X_POTRF_YIELD_GRIDS=1 puts them in: diagnosis of the intermittent
+                  failure that appeared with it, README status) */
+               !dist || yield_on_grids);
     prof_end(3, s_panel, cxf * (double) kb * kb * kb / 3.0, (double) kb * kb * sizeof(T));
   };
 
@@ -1545,6 +1551,15 @@ int DeviceMatrix<T>::wait() {
   DLAF_HIP_CHECK(hipStreamSynchronize(s_low));
   DLAF_HIP_CHECK(hipStreamSynchronize(s_high));
   DLAF_HIP_CHECK(hipMemcpy(info_host, info, sizeof(int), hipMemcpyDeviceToHost));
+  // DLAF_MI355X_INFO_VERBOSE=1: this rank's own status word before the grid agrees on one (diagnosis of the
+  // intermittent "owner did not report its negative pivot" failure of the six-rank test worker, README status)
+  static const bool info_verbose = [] {
+    const char* e = std::getenv("DLAF_MI355X_INFO_VERBOSE");
+    return e && std::atoi(e) != 0;
+  }();
+  if (info_verbose)
+    std::fprintf(stderr, "[dlaf_mi355x] rank (%d,%d) of %dx%d: local info %d (n %ld nb %d)\n", grid->myrow, grid->mycol,
+                 grid->nprow, grid->npcol, *info_host, n, nb);
   if (grid->nranks > 1 && grid->transport) {
       // one value for the whole grid (ScaLAPACK's p?potrf contract; the reference aborts every rank,
     // src/cusolver/assert_info.cu:35-45): v[0] carries the LAPACK index, v[1] the scheduling failure
