@@ -466,13 +466,16 @@ void DeviceMatrix<T>::upload(const T* host, long ld) {
     return;
   const long lds = srows;
   ensure_staging(*this, (size_t) lds * scols);
-  // only the uplo triangle crosses PCIe (the relayout never reads the other one)
+  // only the uplo triangle crosses PCIe (the relayout never reads the other one).  BLOCKING copies: the caller's
+  // array is typically pageable and may be a temporary that goes away the moment this function returns -- an
+  // "async" copy out of pageable memory is only as synchronous as the runtime makes it (the six-rank test worker,
+  // which uploads a temporary, intermittently factored a matrix that was not the one it had passed: README status)
+  DLAF_HIP_CHECK(hipStreamSynchronize(s_high));  // whatever used the staging copy before
   for_each_triangle_block(
       *this,
       [&](long r0, long nr, long c0, long nc) {
-        DLAF_HIP_CHECK(hipMemcpy2DAsync(staging + r0 + c0 * lds, (size_t) lds * sizeof(T), host + r0 + c0 * ld,
-                                        (size_t) ld * sizeof(T), (size_t) nr * sizeof(T), (size_t) nc,
-                                        hipMemcpyHostToDevice, s_high));
+        DLAF_HIP_CHECK(hipMemcpy2D(staging + r0 + c0 * lds, (size_t) lds * sizeof(T), host + r0 + c0 * ld,
+                                   (size_t) ld * sizeof(T), (size_t) nr * sizeof(T), (size_t) nc, hipMemcpyHostToDevice));
       },
       [](long, long, long, long) {});
   launch_to_tiles(layout_args(*this, staging, lds), s_high);
