@@ -18,16 +18,16 @@ and a GPU and fails loudly otherwise.
 """
 from .capi import (DLAFDescriptor, LibraryNotBuilt, lib, lib_path, type_char, version)  # noqa: F401
 from .cholesky import (DeviceMatrix, GeneralDeviceMatrix, Grid, cholesky_factorization, finalize, generalized_to_standard,  # noqa: F401
-                       initialize, make_descriptor, pxhegst, pxpotrf, pxpotrs, pxtrsm, set_random_hermitian_positive_definite, tile_gemm, tile_herk, tile_potrf,
+                       initialize, make_descriptor, potrf_trace, pxhegst, pxpotrf, pxpotrs, pxtrsm, set_random_hermitian_positive_definite, tile_gemm, tile_herk, tile_potrf,
                        tile_trsm, triangular_solver, triangular_solver_device, potrs_device, solver_profile)
 from . import distribution  # noqa: F401
 from .eigensolver import (band_to_tridiagonal, bt_band_to_tridiagonal, bt_reduction_to_band,  # noqa: F401
-                          bt_reduction_to_band_device, eigensolver_profile, get_band_size, hermitian_eigensolver,
+                          bt_reduction_to_band_device, eigensolver_min_band, eigensolver_profile, get_band_size, hermitian_eigensolver,
                           hermitian_generalized_eigensolver, red2band_profile, reduction_to_band,
                           reduction_to_band_device, tridiagonal_eigensolver)
 
 __all__ = ["band_to_tridiagonal", "bt_band_to_tridiagonal", "eigensolver_profile", "hermitian_eigensolver",
-           "hermitian_generalized_eigensolver", "tridiagonal_eigensolver", "bt_reduction_to_band", "bt_reduction_to_band_device", "get_band_size", "red2band_profile",
+           "hermitian_generalized_eigensolver", "tridiagonal_eigensolver", "bt_reduction_to_band", "bt_reduction_to_band_device", "get_band_size", "eigensolver_min_band", "red2band_profile",
            "reduction_to_band", "reduction_to_band_device", "DLAFDescriptor", "DeviceMatrix", "GeneralDeviceMatrix", "Grid", "LibraryNotBuilt", "cholesky_factorization", "distribution",
            "finalize", "generalized_to_standard", "initialize", "lib", "lib_path", "make_descriptor", "pxhegst", "pxpotrf", "pxpotrs", "pxtrsm",
            "set_random_hermitian_positive_definite", "solver_profile", "tile_gemm", "tile_herk", "tile_potrf", "tile_trsm",

@@ -77,6 +77,8 @@ SIGNATURES = {
     "dlaf_mi355x_grid_rekey": (_i, [_i, _i]),
     "dlaf_mi355x_grid_comm_log": (_i, [_i, _i]),
     "dlaf_mi355x_grid_comm_log_read": (_l, [_i, C.POINTER(C.c_long), _l]),
+    "dlaf_mi355x_matrix_local_info": (_i, [_vp]),
+    "dlaf_mi355x_potrf_trace": (_i, [C.POINTER(C.c_ulonglong)]),
     "dlaf_mi355x_cholesky_start": (_i, [_vp]),
     "dlaf_mi355x_cholesky_wait": (_i, [_vp]),
     "dlaf_mi355x_cholesky_factorization_device": (_i, [_vp]),
@@ -158,6 +160,8 @@ SIGNATURES = {
     "dlaf_mi355x_tridiagonal_eigensolver_d": (_i, [_i, _i, _vp, _vp, _vp, _vp, _i]),
     "dlaf_mi355x_eigensolver_profile": (_i, [C.POINTER(C.c_double)]),
     "dlaf_mi355x_get_band_size": (_i, [_i]),
+    "dlaf_mi355x_get_eigensolver_min_band": (_i, []),
+    "dlaf_mi355x_set_eigensolver_min_band": (None, [_i]),
     "dlaf_mi355x_red2band_profile": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dlaf_mi355x_set_random_hpd": (_i, [_i, _ch, _vp, DLAFDescriptor, _i]),
     "dlaf_mi355x_tile_potrf": (_i, [_ch, _ch, _i, _vp, _i]),

@@ -267,6 +267,13 @@ def set_random_hermitian_positive_definite(grid: Grid, a: np.ndarray, n: int, nb
         raise ValueError(f"dlaf_mi355x_set_random_hpd failed with {r}")
 
 
+def potrf_trace():
+    """Diagnosis hook (DLAF_MI355X_POTRF_TRACE=1): the 32 words the last first-diagonal-tile POTRF of this process
+    recorded (kernels_potrf_coop.hip), or None when tracing is off."""
+    out = (C.c_ulonglong * 32)()
+    return list(out) if lib().dlaf_mi355x_potrf_trace(out) == 0 else None
+
+
 class DeviceMatrix:
     """Matrix<T, Device::GPU> of the MI355X build: the local part of a block-cyclic matrix resident
     in HBM in tile layout (reference: matrix/matrix.h:57-357 + MatrixMirror, matrix_mirror.h:137-173).
@@ -318,6 +325,10 @@ class DeviceMatrix:
 
     def wait(self) -> int:
         return lib().dlaf_mi355x_cholesky_wait(self._h)
+
+    def local_info(self) -> int:
+        """This process's own device status word of the last factorization, before the grid agreed on one value."""
+        return lib().dlaf_mi355x_matrix_local_info(self._h)
 
     def residual_against(self, factor: "DeviceMatrix"):
         """check_cholesky of the miniapp (miniapp_cholesky.cpp:408-443) on the device.  `self` must hold the

@@ -8,6 +8,20 @@
 
 namespace dlaf_mi355x {
 
+// Zero device memory and RETURN ONLY WHEN IT IS ZERO.  On this stack hipMemset -- the "synchronous" entry -- returns
+// before its fill kernel has run (measured: 3 us for a call queued behind a 200 ms kernel, tools/memset_sync_probe.hip,
+// profiles/r04_memset_sync_probe.txt), and the fill sits on the null stream, which the library's non-blocking streams do
+// not synchronise with: a status word "zeroed" that way can be zeroed again AFTER a kernel on another stream has
+// written it.  State that kernels on other streams will touch is therefore zeroed with this, or on the stream that
+// uses it.
+inline hipError_t zero_device_now(void* p, size_t bytes) {
+  hipError_t e = hipMemsetAsync(p, 0, bytes, nullptr);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(nullptr);
+  return e;
+}
+
+
 // Block size of the diagonal factorization / inverted diagonal blocks used by the TRSM.
 constexpr int kDiagBlock = 64;
 // *info value stored by a kernel whose bounded inter-workgroup wait expired (workgroups of the cooperative
@@ -124,6 +138,9 @@ template <class T>
 void launch_potrf_coop(T* tile, int ld, int kb, T* winv, int* info, int info_base, unsigned* sync,
                        hipStream_t stream, bool sync_is_zero = false, bool count_strips = true);
 // count_strips: the strips register in the per-compute-unit table the bulk update kernel consults (the POTRF yield)
+// diagnosis hook (DLAF_MI355X_POTRF_TRACE=1): 32 device words the launches of a factorization's FIRST diagonal tile
+// write what their first two strips saw into (null: off); the caller zeroes them on the stream before the launch
+unsigned long long* potrf_coop_trace_buffer();
 inline size_t potrf_coop_sync_words(int kb) {
   const size_t g = (size_t) ((kb + kDiagBlock - 1) / kDiagBlock);
   return g + g * g;

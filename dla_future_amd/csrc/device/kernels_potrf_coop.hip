@@ -252,9 +252,22 @@ __device__ __forceinline__ void coop_mma64_rega(const real_t<T> (&a_re)[16], con
   }
 }
 
+// A strip that leaves without factoring its diagonal block fills ITS block of winv with NaN: on a process grid the
+// tile and winv are broadcast whatever happened, the other ranks do not see this rank's status word, and what they
+// compute from a failed tile must not depend on what a fresh allocation happened to hold (all-zero inverse blocks
+// give a clean "factorization" of garbage; NaN makes every later diagonal tile flag its first pivot).
+template <class T>
+__device__ __forceinline__ void coop_poison_winv(T* Ws) {
+  using R = real_t<T>;
+  const R nan = __builtin_nan("");
+  for (int idx = threadIdx.x; idx < kCB * kCB; idx += kThreads)
+    store_wt(&Ws[idx], make_el<T>(nan, nan));
+}
+
 template <class T>
 __device__ __forceinline__ void potrf_coop_body(T* __restrict__ tile, int ld, int kb, T* __restrict__ winv, int* info,
-                                                int info_base, unsigned* sync, long spin_limit, int prio) {
+                                                int info_base, unsigned* sync, long spin_limit, int prio,
+                                                unsigned long long* trace) {
   using C = CoopCfg<T>;
   using R = real_t<T>;
   using acc_t = typename Mma<R>::acc_t;
@@ -273,8 +286,26 @@ __device__ __forceinline__ void potrf_coop_body(T* __restrict__ tile, int ld, in
   const int g = lane >> 4, c = lane & 15;
   const int rows_s = min(kCB, kb - kCB * s);
 
-  if (*info != 0)
+  // The entry decision is made ONCE per workgroup: the status word may change between the moments the waves of a
+  // strip get here (another strip flagging its pivot while this one is being dispatched), and a workgroup whose
+  // waves took different exits would run its barriers, its LDS hand-offs and -- thread 0 being the only writer of
+  // `info` and of the flags -- its failure path with a wave missing.
+  if (t == 0)
+    wait_slot = (unsigned) __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const unsigned info_on_entry = wait_slot;
+  __syncthreads();  // (wait_slot is reused by the waits below)
+  // (diagnosis hook, DLAF_MI355X_POTRF_TRACE: what the first two strips saw on entry)
+  if (trace != nullptr && s < 2 && lane == 0) {
+    trace[s * 8 + wave * 2] = (1ull << 63) | info_on_entry;
+    trace[s * 8 + wave * 2 + 1] = wall_clock64();
+  }
+  if (info_on_entry != 0) {
+    if (trace != nullptr && s < 2 && t == 0)
+      trace[16 + s * 8 + 6] = 1;  // left at the entry check
+    coop_poison_winv<T>(winv + (long) s * kCB * kCB);
     return;
+  }
   // The strips sit on compute units they share with waves of the bulk update (16 strips cannot own CUs of a device
   // whose every CU holds persistent update workgroups): raised wave priority lets the SIMD's arbiter issue the
   // strip's instructions first, the update waves fill the slots it leaves.
@@ -305,10 +336,15 @@ __device__ __forceinline__ void potrf_coop_body(T* __restrict__ tile, int ld, in
       }
     }
     const unsigned f = coop_wait(&flag[j], 1u, &wait_slot, spin_limit);
+    if (trace != nullptr && s < 2 && j == 0 && (t & 63) == 0)
+      trace[16 + s * 8 + 5] = ((unsigned long long) (t >> 6) << 40) | (1ull << 32) | f;
     if (f != 1u) {
+      if (trace != nullptr && s < 2 && t == 0)
+        trace[16 + s * 8 + 6] = 2;  // left after the owner's flag
       // not positive definite (info already set by the owner), or the spin bound was hit
       if (f == 0xFFFFFFFFu && t == 0)
         atomicCAS(info, 0, kInfoSchedulingFailure);
+      coop_poison_winv<T>(winv + (long) s * kCB * kCB);
       return;
     }
     // ---- X_s = A(s,j) * inv(L_jj)^H ----------------------------------------------------------------
@@ -371,6 +407,7 @@ __device__ __forceinline__ void potrf_coop_body(T* __restrict__ tile, int ld, in
       if (s - j - 1 > 0 && !coop_wait_all(&xflag[(long) j * G + j + 1], s - j - 1, &wait_slot, spin_limit)) {
         if (t == 0)
           atomicCAS(info, 0, kInfoSchedulingFailure);
+        coop_poison_winv<T>(winv + (long) s * kCB * kCB);
         return;
       }
       // ---- A(s,c) -= X_s * X_c^H for c = j+1 .. s: the C block is loaded INTO the accumulators ---------
@@ -477,6 +514,7 @@ __device__ __forceinline__ void potrf_coop_body(T* __restrict__ tile, int ld, in
     if (s - j - 1 > 0 && !coop_wait_all(&xflag[(long) j * G + j + 1], s - j - 1, &wait_slot, spin_limit)) {
       if (t == 0)
         atomicCAS(info, 0, kInfoSchedulingFailure);
+      coop_poison_winv<T>(winv + (long) s * kCB * kCB);
       return;
     }
     // ---- A(s,c) -= X_s * X_c^H for c = j+1 .. s ----------------------------------------------------
@@ -598,10 +636,22 @@ __device__ __forceinline__ void potrf_coop_body(T* __restrict__ tile, int ld, in
       }
     }
     __syncthreads();
+    if (trace != nullptr && s < 2 && t == 0)
+      trace[16 + s * 8 + 0] = (unsigned long long) __builtin_bit_cast(unsigned long long, (double) Lre[0]);
     const int failed = diag_factor_invert<T, PACK>(Lre, Lim, Wre, Wim, jb, 1, &fail_col);
+    if (trace != nullptr && s < 2 && t == 0)
+      trace[16 + s * 8 + 1] = (1ull << 32) | (unsigned) failed;
     if (failed >= 0) {
-      if (t == 0)
-        atomicCAS(info, 0, info_base + kCB * s + failed + 1);
+      if (t == 0) {
+        const int old = atomicCAS(info, 0, info_base + kCB * s + failed + 1);
+        if (trace != nullptr && s < 2) {
+          trace[16 + s * 8 + 2] = (1ull << 32) | (unsigned) old;
+          trace[16 + s * 8 + 3] = wall_clock64();
+          trace[16 + s * 8 + 4] = (1ull << 32) | (unsigned) __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          trace[16 + s * 8 + 6] = 3;  // flagged a pivot
+        }
+      }
+      coop_poison_winv<T>(winv + (long) s * kCB * kCB);
       coop_publish(&flag[s], kCoopFailed, false);
       return;
     }
@@ -623,6 +673,8 @@ __device__ __forceinline__ void potrf_coop_body(T* __restrict__ tile, int ld, in
       store_wt(&Ws[rr + (long) cl * kPD], make_el<T>(wre, wim));
     }
     coop_publish(&flag[s], 1u, false);
+    if (trace != nullptr && s < 2 && t == 0)
+      trace[16 + s * 8 + 6] = 4;  // factored
   }
 }
 
@@ -631,7 +683,8 @@ __device__ __forceinline__ void potrf_coop_body(T* __restrict__ tile, int ld, in
 template <class T>
 __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__ tile, int ld, int kb,
                                                                   T* __restrict__ winv, int* info, int info_base,
-                                                                  unsigned* sync, long spin_limit, int prio, int* cu_busy) {
+                                                                  unsigned* sync, long spin_limit, int prio, int* cu_busy,
+                                                                  unsigned long long* trace) {
   int* mine = nullptr;
   if (cu_busy != nullptr && threadIdx.x == 0) {
     unsigned xcc;
@@ -639,7 +692,9 @@ __global__ __launch_bounds__(kThreads, 2) void potrf_coop_kernel(T* __restrict__
     mine = cu_busy + (xcc * 256u + key);
     atomicAdd(mine, 1);
   }
-  potrf_coop_body<T>(tile, ld, kb, winv, info, info_base, sync, spin_limit, prio);
+  // (registration precedes the workgroup-uniform entry decision of the body: its first barrier)
+  potrf_coop_body<T>(tile, ld, kb, winv, info, info_base, sync, spin_limit, prio, trace);
+  __syncthreads();  // the strip leaves the table when ALL its waves are done, not when wave 0 is
   if (mine != nullptr)
     atomicSub(mine, 1);
 }
@@ -654,6 +709,24 @@ static int coop_wave_prio() {
 }
 
 int* cu_busy_table();  // kernels_update.hip
+
+// DLAF_MI355X_POTRF_TRACE=1 (diagnosis): the launches with info_base == 0 -- the first diagonal tile of a factorization --
+// record what their first two strips saw into 32 device words (potrf_coop_trace_buffer(): zeroed by the caller)
+static unsigned long long* g_potrf_trace = nullptr;
+unsigned long long* potrf_coop_trace_buffer() {
+  static const bool on = [] {
+    const char* e = std::getenv("DLAF_MI355X_POTRF_TRACE");
+    return e && std::atoi(e) != 0;
+  }();
+  if (on && g_potrf_trace == nullptr) {
+    if (hipMalloc(reinterpret_cast<void**>(&g_potrf_trace), 32 * sizeof(unsigned long long)) != hipSuccess ||
+        zero_device_now(g_potrf_trace, 32 * sizeof(unsigned long long)) != hipSuccess) {
+      (void) hipGetLastError();
+      g_potrf_trace = nullptr;
+    }
+  }
+  return g_potrf_trace;
+}
 
 static void fatal_device_config(const char* what) {
   std::fprintf(stderr, "[dlaf_mi355x] %s\n", what);
@@ -673,7 +746,8 @@ void launch_potrf_coop(T* tile, int ld, int kb, T* winv, int* info, int info_bas
   if (!sync_is_zero)
     (void) hipMemsetAsync(sync, 0, sizeof(unsigned) * ((size_t) G + (size_t) G * G), stream);
   hipLaunchKernelGGL((potrf_coop_kernel<T>), dim3((unsigned) G), dim3(kThreads), CoopCfg<T>::LDS_BYTES, stream, tile, ld,
-                     kb, winv, info, info_base, sync, coop_spin_limit(), coop_wave_prio(), count_strips ? cu_busy_table() : nullptr);
+                     kb, winv, info, info_base, sync, coop_spin_limit(), coop_wave_prio(), count_strips ? cu_busy_table() : nullptr,
+                     info_base == 0 ? potrf_coop_trace_buffer() : nullptr);
 }
 
 template <class T>

@@ -604,7 +604,7 @@ int* cu_busy_table() {
   }();
   if (on && g_cu_busy == nullptr) {
     if (hipMalloc(reinterpret_cast<void**>(&g_cu_busy), 8 * 256 * sizeof(int)) != hipSuccess ||
-        hipMemset(g_cu_busy, 0, 8 * 256 * sizeof(int)) != hipSuccess) {
+        zero_device_now(g_cu_busy, 8 * 256 * sizeof(int)) != hipSuccess) {
       (void) hipGetLastError();
       g_cu_busy = nullptr;
     }

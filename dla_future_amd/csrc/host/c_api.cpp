@@ -434,6 +434,21 @@ extern "C" {
 void dlaf_initialize(int, const char**, int argc_dlaf, const char** argv_dlaf) noexcept {
   const bool first = !runtime_initialized();
   runtime_init();
+  // tune parameters (src/init.cpp:211-221: the environment variable first, the command-line option overrides it)
+  if (first) {
+    if (const char* e = std::getenv("DLAF_EIGENSOLVER_MIN_BAND"))
+      set_eigensolver_min_band(std::atoi(e));
+    for (int i = 0; argv_dlaf && i < argc_dlaf; ++i) {
+      static const char opt[] = "--dlaf:eigensolver-min-band";
+      if (!argv_dlaf[i] || std::strncmp(argv_dlaf[i], opt, sizeof(opt) - 1) != 0)
+        continue;
+      const char* v = argv_dlaf[i] + sizeof(opt) - 1;
+      if (*v == '=')
+        set_eigensolver_min_band(std::atoi(v + 1));
+      else if (*v == 0 && i + 1 < argc_dlaf && argv_dlaf[i + 1])
+        set_eigensolver_min_band(std::atoi(argv_dlaf[++i]));
+    }
+  }
   for (int i = 0; first && argv_dlaf && i < argc_dlaf; ++i)
     if (argv_dlaf[i] && std::strcmp(argv_dlaf[i], "--dlaf:print-config") == 0) {
       int dev = -1;
@@ -753,6 +768,12 @@ int dlaf_mi355x_eigensolver_profile(double ms[5]) noexcept {
   return 0;
 }
 
+int dlaf_mi355x_get_eigensolver_min_band(void) noexcept {
+  return eigensolver_min_band();
+}
+void dlaf_mi355x_set_eigensolver_min_band(int b_min) noexcept {
+  set_eigensolver_min_band(b_min);
+}
 int dlaf_mi355x_get_band_size(int nb) noexcept {
   return get_band_size(nb);
 }
@@ -896,6 +917,16 @@ int dlaf_mi355x_cholesky_wait(dlaf_mi355x_matrix_t h) noexcept {
 }
 int dlaf_mi355x_cholesky_factorization_device(dlaf_mi355x_matrix_t h) noexcept {
   WITH_MATRIX(h, return M.factorize();)
+}
+int dlaf_mi355x_matrix_local_info(dlaf_mi355x_matrix_t h) noexcept {
+  WITH_MATRIX(h, return M.local_info;)
+}
+int dlaf_mi355x_potrf_trace(unsigned long long* out) noexcept {
+  unsigned long long* tb = potrf_coop_trace_buffer();
+  if (tb == nullptr || out == nullptr)
+    return 1;
+  (void) hipDeviceSynchronize();
+  return hipMemcpy(out, tb, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 
 int dlaf_mi355x_cholesky_residual(dlaf_mi355x_matrix_t original, dlaf_mi355x_matrix_t factor, double* max_diff,

@@ -59,9 +59,21 @@ void red2band_last_profile(double* ms, double* flops) {
     *flops = g_last_flops;
 }
 
+// tune parameter eigensolver_min_band (include/dlaf/tune.h:71-75,128; default 100): set from DLAF_EIGENSOLVER_MIN_BAND /
+// --dlaf:eigensolver-min-band by dlaf_initialize (src/init.cpp:220) or by dlaf_mi355x_set_eigensolver_min_band
+static int g_eigensolver_min_band = 100;
+int eigensolver_min_band() {
+  return g_eigensolver_min_band;
+}
+void set_eigensolver_min_band(int b_min) {
+  if (b_min < 2)
+    fatal("[dlaf_mi355x] eigensolver_min_band = %d must be >= 2 (get_band_size.h:24)\n", b_min);
+  g_eigensolver_min_band = b_min;
+}
+
 int get_band_size(int nb) {
-  // eigensolver/internal/get_band_size.h:20-31 with the default eigensolver_min_band = 100 (tune.h)
-  constexpr int min_band = 100;
+  // eigensolver/internal/get_band_size.h:20-31: the smallest divisor of nb that is >= eigensolver_min_band, else nb
+  const int min_band = g_eigensolver_min_band;
   for (int div = nb / min_band; div >= 2; --div)
     if (nb % div == 0)
       return nb / div;

@@ -13,8 +13,10 @@ inline T make_host_el(double re) {
     return (T) re;
 }
 
-// eigensolver/internal/get_band_size.h:20-31 (eigensolver_min_band = 100)
+// eigensolver/internal/get_band_size.h:20-31 with the tune parameter eigensolver_min_band (tune.h:128, default 100)
 int get_band_size(int nb);
+int eigensolver_min_band();
+void set_eigensolver_min_band(int b_min);
 
 // A (uplo L, tile layout) <- band + reflectors; taus_host: n - band - 1 values (all of them on every rank), may be null
 template <class T>

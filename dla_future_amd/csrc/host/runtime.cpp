@@ -294,7 +294,10 @@ void DeviceMatrix<T>::create(Grid* g, char uplo_, long n_, int nb_, int isrc, in
     bulk_slots = (long) prop.multiProcessorCount * update_blocks_per_cu<T>();
   }
   DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&info), sizeof(int)));
-  DLAF_HIP_CHECK(hipMemset(info, 0, sizeof(int)));
+  // NOT hipMemset: that call returns before its fill has run, on the null stream, which the streams below do not
+  // synchronise with -- the fill could land after the first diagonal tile's POTRF had flagged its pivot, and the
+  // factorization of a matrix that is not positive definite came back with info 0 (README, round 4).
+  DLAF_HIP_CHECK(zero_device_now(info, sizeof(int)));
   // Flags and counters of the launches that need them: a slice of 16 words (8 dequeue heads + 8 pacing counters)
   // per persistent update launch, then a slice per diagonal tile for the cooperative POTRF.  The whole buffer is
   // zeroed ONCE per factorization and every launch gets a slice of its own: no fill kernel in front of every
@@ -466,16 +469,14 @@ void DeviceMatrix<T>::upload(const T* host, long ld) {
     return;
   const long lds = srows;
   ensure_staging(*this, (size_t) lds * scols);
-  // only the uplo triangle crosses PCIe (the relayout never reads the other one).  BLOCKING copies: the caller's
-  // array is typically pageable and may be a temporary that goes away the moment this function returns -- an
-  // "async" copy out of pageable memory is only as synchronous as the runtime makes it (the six-rank test worker,
-  // which uploads a temporary, intermittently factored a matrix that was not the one it had passed: README status)
-  DLAF_HIP_CHECK(hipStreamSynchronize(s_high));  // whatever used the staging copy before
+  // only the uplo triangle crosses PCIe (the relayout never reads the other one); the copies, the relayout and the
+  // closing synchronisation share one stream, so the caller's array is free to go when this returns
   for_each_triangle_block(
       *this,
       [&](long r0, long nr, long c0, long nc) {
-        DLAF_HIP_CHECK(hipMemcpy2D(staging + r0 + c0 * lds, (size_t) lds * sizeof(T), host + r0 + c0 * ld,
-                                   (size_t) ld * sizeof(T), (size_t) nr * sizeof(T), (size_t) nc, hipMemcpyHostToDevice));
+        DLAF_HIP_CHECK(hipMemcpy2DAsync(staging + r0 + c0 * lds, (size_t) lds * sizeof(T), host + r0 + c0 * ld,
+                                        (size_t) ld * sizeof(T), (size_t) nr * sizeof(T), (size_t) nc,
+                                        hipMemcpyHostToDevice, s_high));
       },
       [](long, long, long, long) {});
   launch_to_tiles(layout_args(*this, staging, lds), s_high);
@@ -753,6 +754,8 @@ void DeviceMatrix<T>::factorize_async() {
   }
   DLAF_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int), s_panel));
   DLAF_HIP_CHECK(hipMemsetAsync(coop_sync, 0, sizeof(unsigned) * coop_sync_words, s_panel));
+  if (unsigned long long* tb = potrf_coop_trace_buffer())
+    DLAF_HIP_CHECK(hipMemsetAsync(tb, 0, 32 * sizeof(unsigned long long), s_panel));
   size_t next_update_slice = 0;
   // DLAF_MI355X_SYNC_POOL=0: a fill kernel per launch instead (A/B)
   const bool sync_pool = [] {
@@ -875,6 +878,7 @@ void DeviceMatrix<T>::factorize_async() {
       launch_update(ua, s, role, bulk_slots, cnt, zero, reserve);
     else
       launch_update(ua, s, role, reserve > 0 ? std::max<long>(8, bulk_slots - reserve) : 0, cnt, zero);
+    DLAF_HIP_CHECK(hipGetLastError());
     prof_end(pk, s, fl, by);
   };
 
@@ -915,13 +919,9 @@ void DeviceMatrix<T>::factorize_async() {
     }
     prof_begin(2, ts);
     launch_trsm(ta, ts);
+    DLAF_HIP_CHECK(hipGetLastError());
     prof_end(2, ts, fl, by);
   };
-
-  static const bool yield_on_grids = [] {
-    const char* e = std::getenv("DLAF_MI355X_POTRF_YIELD_GRIDS");
-    return e && std::atoi(e) != 0;
-  }();
 
   // diagonal tile k on its owner (s_panel); the inverted diagonal blocks alternate between two buffers
   // because POTRF(k+1) may run while TRSM(k) still reads those of step k
@@ -935,10 +935,8 @@ void DeviceMatrix<T>::factorize_async() {
     prof_begin(3, s_panel);
     potrf_tile(tile(rows.local_of(k), cols.local_of(k)), nb, kb, winv_of(k), info, (int) (k * nb),
                coop_sync + 16 * coop_sync_update_slices + coop_sync_potrf_words * (size_t) k, s_panel, sync_pool,
-               /* the POTRF yield: one process only -- measured there; on process grids the strips
-                  stay out of the table (DLAF_MI355X_POTRF_YIELD_GRIDS=1 puts them in: diagnosis of the intermittent
-                  failure that appeared with it, README status) */
-               !dist || yield_on_grids);
+               /* the strips register for the POTRF yield, on one process and on grids */ true);
+    DLAF_HIP_CHECK(hipGetLastError());  // (a launch that did not happen leaves winv unwritten and info 0)
     prof_end(3, s_panel, cxf * (double) kb * kb * kb / 3.0, (double) kb * kb * sizeof(T));
   };
 
@@ -1554,6 +1552,7 @@ int DeviceMatrix<T>::wait() {
   DLAF_HIP_CHECK(hipStreamSynchronize(s_low));
   DLAF_HIP_CHECK(hipStreamSynchronize(s_high));
   DLAF_HIP_CHECK(hipMemcpy(info_host, info, sizeof(int), hipMemcpyDeviceToHost));
+  local_info = *info_host;
   // DLAF_MI355X_INFO_VERBOSE=1: this rank's own status word before the grid agrees on one (diagnosis of the
   // intermittent "owner did not report its negative pivot" failure of the six-rank test worker, README status)
   static const bool info_verbose = [] {

@@ -198,6 +198,7 @@ struct DeviceMatrix : MatrixBase {
   // the device flags: every kernel that saw the failing diagonal tile stored the same index, the others 0;
   // the scheduling-failure code wins over everything) -- collective, like the factorization itself.
   int wait();
+  int local_info = 0;  // this rank's own device status word of the last wait(), before the grid agreed on one
   // one tile of the device copy (global tile indices of the caller's matrix, not of the transposed view)
   // to / from a dense host array; returns false when this rank does not own the tile
   bool fetch_tile(long gi, long gj, T* host, long ld);

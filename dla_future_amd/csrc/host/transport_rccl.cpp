@@ -33,7 +33,7 @@ public:
     DLAF_NCCL_CHECK(ncclCommSplit(world_, myrow, mycol, &row_, nullptr));
     DLAF_NCCL_CHECK(ncclCommSplit(world_, mycol, myrow, &col_, nullptr));
     DLAF_HIP_CHECK(hipMalloc(&token_, sizeof(int)));
-    DLAF_HIP_CHECK(hipMemset(token_, 0, sizeof(int)));
+    DLAF_HIP_CHECK(zero_device_now(token_, sizeof(int)));  // (hipMemset returns before its fill has run: device_api.hpp)
     DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&scal_dev_), sizeof(double) * kScalars));
     DLAF_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&scal_host_), sizeof(double) * kScalars, hipHostMallocDefault));
     DLAF_HIP_CHECK(hipStreamCreateWithFlags(&scal_stream_, hipStreamNonBlocking));

@@ -14,8 +14,16 @@ from .cholesky import DeviceMatrix, GeneralDeviceMatrix, Grid, _ld_of, _ptr, mak
 
 
 def get_band_size(nb: int) -> int:
-    """include/dlaf/eigensolver/internal/get_band_size.h:20-31 (eigensolver_min_band = 100)."""
+    """include/dlaf/eigensolver/internal/get_band_size.h:20-31 with the tune parameter eigensolver_min_band."""
     return lib().dlaf_mi355x_get_band_size(nb)
+
+
+def eigensolver_min_band(b_min: int | None = None) -> int:
+    """getTuneParameters().eigensolver_min_band (include/dlaf/tune.h:128; DLAF_EIGENSOLVER_MIN_BAND, src/init.cpp:220):
+    returns the current value, after setting it when `b_min` is given."""
+    if b_min is not None:
+        lib().dlaf_mi355x_set_eigensolver_min_band(int(b_min))
+    return lib().dlaf_mi355x_get_eigensolver_min_band()
 
 
 def reduction_to_band(grid: Grid, a: np.ndarray, nb: int, band_size: int, isrc: int = 0, jsrc: int = 0,

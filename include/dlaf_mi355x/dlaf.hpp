@@ -443,6 +443,23 @@ void generalized_to_standard(blas::Uplo uplo, Matrix<T, Device::CPU>& mat_a, Mat
 // The reference returns the taus as a Matrix<T, Device::CPU> distributed over the process columns; here every
 // process gets all n - band_size - 1 of them as a std::vector (entry j belongs to the reflector in global column j).
 inline SizeType get_band_size(SizeType nb) { return dlaf_mi355x_get_band_size((int) nb); }
+
+// dlaf::getTuneParameters() (include/dlaf/tune.h:128-160): the parameters this build honours.  The reference's tests
+// assign to the field (test/unit/eigensolver/test_eigensolver.cpp:142 `getTuneParameters().eigensolver_min_band = b_min`),
+// so the field is a proxy onto the library's value.
+struct TuneParameters {
+  struct MinBand {
+    operator SizeType() const { return dlaf_mi355x_get_eigensolver_min_band(); }
+    MinBand& operator=(SizeType b_min) {
+      dlaf_mi355x_set_eigensolver_min_band((int) b_min);
+      return *this;
+    }
+  } eigensolver_min_band;
+};
+inline TuneParameters& getTuneParameters() {
+  static TuneParameters params;
+  return params;
+}
 namespace eigensolver::internal {
 template <Backend B, class T>
 std::vector<T> reduction_to_band(comm::CommunicatorGrid& grid, Matrix<T, Device::GPU>& mat_a, SizeType band_size) {

@@ -86,6 +86,13 @@ DLAF_EXTERN_C int dlaf_mi355x_matrix_fetch_tile(dlaf_mi355x_matrix_t m, long gi,
 DLAF_EXTERN_C int dlaf_mi355x_cholesky_start(dlaf_mi355x_matrix_t m) DLAF_NOEXCEPT;
 DLAF_EXTERN_C int dlaf_mi355x_cholesky_wait(dlaf_mi355x_matrix_t m) DLAF_NOEXCEPT;
 DLAF_EXTERN_C int dlaf_mi355x_cholesky_factorization_device(dlaf_mi355x_matrix_t m) DLAF_NOEXCEPT;
+/* This process's OWN device status word of the last wait / factorization, before the grid agreed on one value
+ * (the reference aborts every rank, src/cusolver/assert_info.cu:35-45; here the smallest positive LAPACK index over
+ * the grid is returned everywhere).  A test uses it to assert that the owner of a non-SPD diagonal tile flagged it. */
+DLAF_EXTERN_C int dlaf_mi355x_matrix_local_info(dlaf_mi355x_matrix_t m) DLAF_NOEXCEPT;
+/* Diagnosis hook (DLAF_MI355X_POTRF_TRACE=1): what the first two strips of the last first-diagonal-tile POTRF of
+ * this process saw (32 words, kernels_potrf_coop.hip); returns 0, or 1 when tracing is off. */
+DLAF_EXTERN_C int dlaf_mi355x_potrf_trace(unsigned long long* out_32_words) DLAF_NOEXCEPT;
 /* Residual checker of the miniapp (miniapp/miniapp_cholesky.cpp:408-443 check_cholesky with
  * auxiliary/norm max_norm) on the device: `original` holds the input matrix and is OVERWRITTEN with
  * A - L L^H (uplo triangle); *max_diff = max|A - L L^H|, *max_a = max|A| over the whole grid (MAX-reduced
@@ -231,7 +238,12 @@ DLAF_EXTERN_C int dlaf_mi355x_bt_reduction_to_band_c(int context, int band_size,
 DLAF_EXTERN_C int dlaf_mi355x_bt_reduction_to_band_z(int context, int band_size, dlaf_complex_z* c,
                                                      struct DLAF_descriptor descc, const dlaf_complex_z* v,
                                                      struct DLAF_descriptor descv, const dlaf_complex_z* taus) DLAF_NOEXCEPT;
-/* get_band_size (include/dlaf/eigensolver/internal/get_band_size.h:20-31, eigensolver_min_band = 100): the band the
+/* Tune parameter eigensolver_min_band (include/dlaf/tune.h:71-75,128; default 100).  dlaf_initialize reads
+ * DLAF_EIGENSOLVER_MIN_BAND and --dlaf:eigensolver-min-band like src/init.cpp:220; the setter is what the reference's
+ * tests do with getTuneParameters().eigensolver_min_band (test/unit/eigensolver/test_eigensolver.cpp:142). b_min >= 2. */
+DLAF_EXTERN_C int dlaf_mi355x_get_eigensolver_min_band(void) DLAF_NOEXCEPT;
+DLAF_EXTERN_C void dlaf_mi355x_set_eigensolver_min_band(int b_min) DLAF_NOEXCEPT;
+/* get_band_size (include/dlaf/eigensolver/internal/get_band_size.h:20-31, tune parameter eigensolver_min_band): the band the
  * reference's eigensolver picks for a block size (128 for nb = 512) */
 DLAF_EXTERN_C int dlaf_mi355x_get_band_size(int nb) DLAF_NOEXCEPT;
 /* device time (ms, HIP events) and whole-grid flops in the reference miniapps' models (2 (2/3 n^3 - n^2 nb), resp.

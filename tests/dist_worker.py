@@ -169,8 +169,9 @@ def main():
             os.environ["DLAF_MI355X_SCHEDULE"] = sched0
         # not positive definite: every rank must report the SAME LAPACK info (the reference aborts every rank,
         # src/cusolver/assert_info.cu:35-45, lapack/tile.h:374-378); nobody hangs, nobody returns 0
-        for t, uplo, n, nb, bad in [("d", "L", 400, 64, 300), ("d", "U", 400, 64, 300), ("z", "L", 200, 32, 77),
-                                    ("d", "L", 400, 128, 0)]:
+        # DIST_WORKER_NONSPD_REPEAT: the cases are run that many times (diagnosis of an intermittent failure; default 1)
+        nonspd_cases = [("d", "L", 400, 64, 300), ("d", "U", 400, 64, 300), ("z", "L", 200, 32, 77), ("d", "L", 400, 128, 0)]
+        for t, uplo, n, nb, bad in nonspd_cases * int(os.environ.get("DIST_WORKER_NONSPD_REPEAT", "1")):
             dt = oracle.DTYPES[t]
             sr, sc = max(0, nprow - 1), min(1, npcol - 1)
             a0 = oracle.set_random_hpd(n, nb, dt)
@@ -186,7 +187,22 @@ def main():
             # device-resident entry: same contract
             m = dlaf.DeviceMatrix(grid, dt, uplo, n, nb, sr, sc)
             m.upload(np.asfortranarray(oracle.scatter(a0, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)]))
+            # the owner of the bad pivot's tile: the device holds the -1 BEFORE the factorization, and its own status
+            # word says bad + 1 after it -- whichever fires names the layer (staging / the tile kernel / the agreement)
+            tb = bad // nb
+            owner = (grid.myrow, grid.mycol) == ((tb + sr) % nprow, (tb + sc) % npcol)
+            # (DIST_WORKER_NONSPD_PRECHECK=0 leaves the fetch out: it synchronises the device between upload and factorize)
+            before = m.fetch_tile(tb, tb) if os.environ.get("DIST_WORKER_NONSPD_PRECHECK", "1") != "0" else None
+            ok &= said((before is not None) == owner or before is None, f"fetch_tile({tb},{tb}) disagrees with the owner formula")
+            if before is not None:
+                ok &= said(before[bad % nb, bad % nb] == -1.0,
+                           f"resident non-SPD {t}{uplo} n={n} nb={nb}: tile ({tb},{tb}) holds {before[bad % nb, bad % nb]} "
+                           f"at the bad pivot after upload(), expected -1")
             r_info = m.factorize()
+            if owner:
+                ok &= said(m.local_info() == bad + 1,
+                           f"resident non-SPD {t}{uplo} n={n} nb={nb}: owner's own status word {m.local_info()}, expected "
+                           f"{bad + 1}; trace {[hex(w) for w in (dlaf.potrf_trace() or [])]}")
             ok &= said(r_info == bad + 1, f"resident non-SPD {t}{uplo} n={n} nb={nb}: factorize() returned {r_info}, expected {bad + 1}")
             m.close()
         # device-side residual checker with the MAX reduction over the grid (miniapp check_cholesky)
