@@ -79,6 +79,7 @@ SIGNATURES = {
     "dlaf_mi355x_grid_comm_log_read": (_l, [_i, C.POINTER(C.c_long), _l]),
     "dlaf_mi355x_matrix_local_info": (_i, [_vp]),
     "dlaf_mi355x_potrf_trace": (_i, [C.POINTER(C.c_ulonglong)]),
+    "dlaf_mi355x_update_launch_stats": (_i, [C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "dlaf_mi355x_cholesky_start": (_i, [_vp]),
     "dlaf_mi355x_cholesky_wait": (_i, [_vp]),
     "dlaf_mi355x_cholesky_factorization_device": (_i, [_vp]),

@@ -274,6 +274,14 @@ def potrf_trace():
     return list(out) if lib().dlaf_mi355x_potrf_trace(out) == 0 else None
 
 
+def update_launch_stats():
+    """(persistent, exclusive): trailing-update launches of this process so far in persistent form / with exclusive
+    compute units."""
+    a, b = C.c_long(0), C.c_long(0)
+    lib().dlaf_mi355x_update_launch_stats(C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
 class DeviceMatrix:
     """Matrix<T, Device::GPU> of the MI355X build: the local part of a block-cyclic matrix resident
     in HBM in tile layout (reference: matrix/matrix.h:57-357 + MatrixMirror, matrix_mirror.h:137-173).

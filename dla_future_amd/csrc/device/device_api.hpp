@@ -138,6 +138,8 @@ template <class T>
 void launch_potrf_coop(T* tile, int ld, int kb, T* winv, int* info, int info_base, unsigned* sync,
                        hipStream_t stream, bool sync_is_zero = false, bool count_strips = true);
 // count_strips: the strips register in the per-compute-unit table the bulk update kernel consults (the POTRF yield)
+// update launches of this process so far in persistent form, and of those with exclusive compute units
+void update_launch_stats(long* persistent, long* exclusive);
 // diagnosis hook (DLAF_MI355X_POTRF_TRACE=1): 32 device words the launches of a factorization's FIRST diagonal tile
 // write what their first two strips saw into (null: off); the caller zeroes them on the stream before the launch
 unsigned long long* potrf_coop_trace_buffer();

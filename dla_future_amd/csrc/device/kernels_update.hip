@@ -615,6 +615,14 @@ int* cu_busy_table() {
 // what the probe launch of update_kernels_init() found: XCDs and compute units per XCD (0: no probe, no exclusive mode)
 static int g_probe_xcds = 0, g_probe_cus_per_xcd = 0, g_probe_engines = 1;
 
+// launches of this process in persistent form / of those with exclusive compute units (tests assert that a forced
+// reservation took the path it was meant to take)
+static long g_launch_stats[2] = {0, 0};
+void update_launch_stats(long* persistent, long* exclusive) {
+  *persistent = g_launch_stats[0];
+  *exclusive = g_launch_stats[1];
+}
+
 // DLAF_MI355X_STEAL=0: a persistent workgroup stops when its own queue is empty (A/B)
 static bool update_steal() {
   static const bool on = [] {
@@ -705,9 +713,11 @@ void launch_update(const UpdateArgs<T>& a, hipStream_t stream, int role, long ma
     mp.kphase_ticks = kphase_ticks<T>((int) (grid));
     mp.steal = (update_steal() && !mp.lockstep) ? 1 : 0;
     mp.cu_busy = (role == 0) ? g_cu_busy : nullptr;
+    ++g_launch_stats[0];
     if (excl_rank > 0) {
       mp.excl_rank = (int) excl_rank;
       mp.excl_budget = (unsigned) excl_slots;
+      ++g_launch_stats[1];
     }
     if (!counters_are_zero)
       (void) hipMemsetAsync(counters, 0, 16 * sizeof(unsigned), stream);

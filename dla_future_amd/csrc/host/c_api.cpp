@@ -921,6 +921,15 @@ int dlaf_mi355x_cholesky_factorization_device(dlaf_mi355x_matrix_t h) noexcept {
 int dlaf_mi355x_matrix_local_info(dlaf_mi355x_matrix_t h) noexcept {
   WITH_MATRIX(h, return M.local_info;)
 }
+int dlaf_mi355x_update_launch_stats(long* persistent, long* exclusive) noexcept {
+  long a = 0, b = 0;
+  update_launch_stats(&a, &b);
+  if (persistent)
+    *persistent = a;
+  if (exclusive)
+    *exclusive = b;
+  return 0;
+}
 int dlaf_mi355x_potrf_trace(unsigned long long* out) noexcept {
   unsigned long long* tb = potrf_coop_trace_buffer();
   if (tb == nullptr || out == nullptr)

@@ -398,8 +398,28 @@ int hermitian_eigensolver_device(DeviceMatrix<T>& A, real_t<T>* w_host, GeneralM
     fatal("[dlaf_mi355x] eigensolver: the eigenvector matrix must be n x n with A's block size and row source rank\n");
   const int band = get_band_size(nb);  // eigensolver/impl.h:41
   hipStream_t s = A.s_high;
+  // a stage's status is made the same on every rank before anybody acts on it: a rank that left alone would leave
+  // the others inside the next collective
+  auto agreed = [&](int info) {
+    if (g->nranks > 1 && g->transport) {
+      double v[2] = {info > 0 ? (double) info : 0.0, info < 0 ? 1.0 : 0.0};
+      g->transport->allreduce_max(v, 2, g->nprow, g->npcol, g->myrow, g->mycol);
+      info = v[1] > 0 ? kInfoSchedulingFailure : (int) v[0];
+    }
+    return info;
+  };
+  // stages 2 and 3 run replicated: every rank holds the n x n reflector matrix (T), the n x n real eigenvector matrix
+  // and the divide & conquer workspaces (4 n^2 real) -- say so instead of failing inside an allocation
+  {
+    size_t free_b = 0, total_b = 0;
+    DLAF_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+    const double need = (double) n * n * (sizeof(T) + 5.0 * sizeof(R)) + (double) n * bt_aligned_ld(n) / g->npcol * sizeof(T);
+    if (need > 0.95 * (double) free_b)
+      fatal("[dlaf_mi355x] eigensolver: n = %ld needs %.1f GiB per rank for the replicated stages (band_to_tridiagonal, "
+            "tridiagonal_eigensolver), %.1f GiB are free\n", n, need / 1073741824.0, (double) free_b / 1073741824.0);
+  }
   std::vector<T> taus((size_t) std::max<long>(0, n - band - 1) + 1);
-  int info = reduction_to_band_device(A, band, taus.data());
+  int info = agreed(reduction_to_band_device(A, band, taus.data()));
   {
     double ms = 0, fl = 0;
     red2band_last_profile(&ms, &fl);
@@ -410,7 +430,13 @@ int hermitian_eigensolver_device(DeviceMatrix<T>& A, real_t<T>* w_host, GeneralM
   R* d = ealloc<R>((size_t) n);
   R* e = ealloc<R>((size_t) n);
   T* v = ealloc<T>((size_t) n * n);
-  info = band_to_tridiag_device(A, band, d, e, v, n);
+  info = agreed(band_to_tridiag_device(A, band, d, e, v, n));
+  if (info != 0) {
+    for (R* q : {d, e})
+      DLAF_HIP_CHECK(hipFree(q));
+    DLAF_HIP_CHECK(hipFree(v));
+    return info;
+  }
   R* wd = ealloc<R>((size_t) n);
   R* zr = ealloc<R>((size_t) n * n);
   {
@@ -436,7 +462,7 @@ int hermitian_eigensolver_device(DeviceMatrix<T>& A, real_t<T>* w_host, GeneralM
     DLAF_HIP_CHECK(hipFree(q));
   DLAF_HIP_CHECK(hipFree(v));
   DLAF_HIP_CHECK(hipFree(el_alloc));
-  info = bt_reduction_to_band_device(band, C, A, taus.data());
+  info = agreed(bt_reduction_to_band_device(band, C, A, taus.data()));
   {
     double ms = 0, fl = 0;
     red2band_last_profile(&ms, &fl);

@@ -51,7 +51,11 @@ public:
   }
   ~PeerTransport() override {
     (void) hipDeviceSynchronize();
-    for (hipEvent_t e : twins_)
+    for (const Twin& t : twins_) {
+      (void) hipEventDestroy(t.twin);
+      (void) hipEventDestroy(t.marker);
+    }
+    for (hipEvent_t e : markers_)
       (void) hipEventDestroy(e);
     for (auto& kv : mappings_)
       (void) hipIpcCloseMemHandle(kv.second);
@@ -100,7 +104,7 @@ public:
       if (msg.bytes != bytes)
         fatal("[dlaf_mi355x] peer transport: root sends %llu bytes, receiver expects %zu\n", msg.bytes, bytes);
       const char* peer = static_cast<const char*>(mapping(msg.mem));
-      DLAF_HIP_CHECK(hipStreamWaitEvent(stream, opened(msg.ready), 0));
+      wait_opened(msg.ready, stream);
       const hipError_t ce = hipMemcpyAsync(recv, peer + msg.offset, bytes, hipMemcpyDeviceToDevice, stream);
       if (ce != hipSuccess) {
         hipDeviceptr_t b0 = nullptr, b1 = nullptr;
@@ -125,7 +129,7 @@ public:
         h = my_done;
       control(axis, r, &h, sizeof(h));
       if (my_index == root)
-        DLAF_HIP_CHECK(hipStreamWaitEvent(stream, opened(h), 0));
+        wait_opened(h, stream);
     }
     if (st)
       DLAF_HIP_CHECK(hipEventRecord(st->free_ev, stream));
@@ -165,14 +169,25 @@ private:
   // One interprocess event per record: on this stack another process can wait for an interprocess event's FIRST record
   // only -- a wait on the opened twin fails with "invalid argument" once the owner has recorded the event a second time
   // (measured with rings of 64 and of 4 events: the first reuse of a slot).  An interprocess event costs 32 kernel-driver
-  // signals (a process owns 4096), so the owner destroys its events 16 broadcasts later, when every wait on them has long
-  // been enqueued (the closing control message of a broadcast orders that).
+  // signals (a process owns 4096), so events are retired -- but by GPU progress, not by count: the host thread runs many
+  // steps ahead of the device, and the closing control message of a broadcast only says that the peers' waits have been
+  // ENQUEUED.  An own event goes when it is at least 16 broadcasts old AND its record has executed (a wait on a signalled
+  // event has nothing left to wait for); past kMaxOwn outstanding events the oldest is waited for (bound: kMaxOwn own +
+  // kMaxTwins opened events = 112 x 32 = 3584 signals per process over both communicators).
+  static constexpr size_t kMinAge = 16, kMaxOwn = 48, kMaxTwins = 64;
   hipEvent_t fresh(hipIpcEventHandle_t* h) {
     hipEvent_t e = nullptr;
     DLAF_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventInterprocess));
     DLAF_HIP_CHECK(hipIpcGetEventHandle(h, e));
     mine_.push_back(e);
-    if (mine_.size() > 16) {
+    while (mine_.size() > kMinAge) {
+      hipError_t q = hipEventQuery(mine_.front());
+      if (q == hipErrorNotReady && mine_.size() > kMaxOwn)
+        q = hipEventSynchronize(mine_.front());
+      if (q != hipSuccess) {
+        (void) hipGetLastError();
+        break;
+      }
       (void) hipEventDestroy(mine_.front());
       mine_.erase(mine_.begin());
     }
@@ -180,16 +195,36 @@ private:
   }
   // A handle is opened anew for every wait: on this stack a wait on an opened event fails with "invalid argument"
   // once the owner has recorded the event again after the handle was opened (measured: the first reuse of a ring
-  // slot).  The opened twins are destroyed a few dozen broadcasts later, when their waits have long been enqueued.
-  hipEvent_t opened(const hipIpcEventHandle_t& h) {
-    hipEvent_t e = nullptr;
-    DLAF_HIP_CHECK(hipIpcOpenEventHandle(&e, h));
-    twins_.push_back(e);
-    if (twins_.size() > 32) {
-      (void) hipEventDestroy(twins_.front());
+  // slot).  An opened twin is dropped when a marker recorded on the waiting stream right after the wait has completed,
+  // i.e. when the wait itself has executed (see wait_opened).
+  struct Twin {
+    hipEvent_t twin, marker;
+  };
+  void wait_opened(const hipIpcEventHandle_t& h, hipStream_t stream) {
+    Twin t{nullptr, nullptr};
+    DLAF_HIP_CHECK(hipIpcOpenEventHandle(&t.twin, h));
+    DLAF_HIP_CHECK(hipStreamWaitEvent(stream, t.twin, 0));
+    if (!markers_.empty()) {
+      t.marker = markers_.back();
+      markers_.pop_back();
+    }
+    else {
+      DLAF_HIP_CHECK(hipEventCreateWithFlags(&t.marker, hipEventDisableTiming));
+    }
+    DLAF_HIP_CHECK(hipEventRecord(t.marker, stream));
+    twins_.push_back(t);
+    while (!twins_.empty()) {
+      hipError_t q = hipEventQuery(twins_.front().marker);
+      if (q == hipErrorNotReady && twins_.size() > kMaxTwins)
+        q = hipEventSynchronize(twins_.front().marker);
+      if (q != hipSuccess) {
+        (void) hipGetLastError();
+        break;
+      }
+      (void) hipEventDestroy(twins_.front().twin);
+      markers_.push_back(twins_.front().marker);
       twins_.erase(twins_.begin());
     }
-    return e;
   }
 
   struct Staging {
@@ -207,7 +242,8 @@ private:
   void* user_;
   std::vector<hipEvent_t> mine_;
   std::map<std::string, void*> mappings_;
-  std::vector<hipEvent_t> twins_;
+  std::vector<Twin> twins_;
+  std::vector<hipEvent_t> markers_;
 };
 
 }  // namespace

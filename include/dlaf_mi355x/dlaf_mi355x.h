@@ -90,6 +90,10 @@ DLAF_EXTERN_C int dlaf_mi355x_cholesky_factorization_device(dlaf_mi355x_matrix_t
  * (the reference aborts every rank, src/cusolver/assert_info.cu:35-45; here the smallest positive LAPACK index over
  * the grid is returned everywhere).  A test uses it to assert that the owner of a non-SPD diagonal tile flagged it. */
 DLAF_EXTERN_C int dlaf_mi355x_matrix_local_info(dlaf_mi355x_matrix_t m) DLAF_NOEXCEPT;
+/* Trailing-update launches of this process so far that ran in persistent form (work items pulled from queues, workgroup
+ * slots left to the kernels beside them) and, of those, the ones that vacated exclusive compute units -- lets a test
+ * assert that a reservation took the path it was meant to take. */
+DLAF_EXTERN_C int dlaf_mi355x_update_launch_stats(long* persistent, long* exclusive) DLAF_NOEXCEPT;
 /* Diagnosis hook (DLAF_MI355X_POTRF_TRACE=1): what the first two strips of the last first-diagonal-tile POTRF of
  * this process saw (32 words, kernels_potrf_coop.hip); returns 0, or 1 when tracing is off. */
 DLAF_EXTERN_C int dlaf_mi355x_potrf_trace(unsigned long long* out_32_words) DLAF_NOEXCEPT;

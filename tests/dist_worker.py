@@ -132,7 +132,7 @@ def main():
                 info = dlaf.cholesky_factorization(grid, uplo, loc, nb, sr, sc, n=n)
                 ev = grid.comm_log_events()
                 grid.comm_log(False)
-                ok &= said(info == 0, "info == 0 (line 135)")
+                ok &= said(info == 0, f"info == 0 (schedule {sched}, {uplo} n={n} nb={nb})")
                 allev = [None] * dist.get_world_size()
                 dist.all_gather_object(allev, (grid.myrow, grid.mycol, ev))
                 if rank == 0:
@@ -167,6 +167,53 @@ def main():
         os.environ.pop("DLAF_MI355X_SCHEDULE", None)
         if sched0 is not None:
             os.environ["DLAF_MI355X_SCHEDULE"] = sched0
+        # The grid order with the reservation a DEVICE-SIDE transport makes (RCCL kernels beside the bulk update:
+        # DLAF_MI355X_COMM_SLOTS) forced onto this host-side one -- the path the first real 2 x 4 RCCL run takes
+        # (replaces cholesky/impl.h:223-304) -- at a size whose bulk launches have more work items than the GPU has
+        # workgroup slots, so that they really run in persistent form: POTRF strips (2 x 128 / 64 = 4 slots) + 60 = one
+        # whole round over the shader engines -> EXCLUSIVE compute units (runtime.cpp `update`), + 28 = 32 -> free slots.
+        # Checked like the miniapp (residual on the device, MAX over the grid) and by the identical-sequence property
+        # of the communicators.
+        if os.environ.get("DIST_WORKER_RESERVED", "1") != "0" and os.environ.get("DLAF_MI355X_SCHEDULE") in (None, "early"):
+            n, nb = 12288, 128
+            sr, sc = max(0, nprow - 1), min(1, npcol - 1)
+            rows, cols = grid.local_shape(n, nb, sr, sc)
+            loc = np.zeros((max(1, rows), max(1, cols)), order="F")[:rows, :cols]
+            dlaf.set_random_hermitian_positive_definite(grid, loc, n, nb, sr, sc)
+            for uplo, comm_slots, want_exclusive in (("L", "60", True), ("U", "28", False)):
+                os.environ["DLAF_MI355X_COMM_SLOTS"] = comm_slots
+                orig = dlaf.DeviceMatrix(grid, np.float64, uplo, n, nb, sr, sc)
+                fact = dlaf.DeviceMatrix(grid, np.float64, uplo, n, nb, sr, sc)
+                orig.upload(loc)
+                fact.copy_from(orig)
+                p0, x0 = dlaf.update_launch_stats()
+                grid.comm_log(True)
+                info = fact.factorize()
+                ev = grid.comm_log_events()
+                grid.comm_log(False)
+                p1, x1 = dlaf.update_launch_stats()
+                ok &= said(info == 0, f"reserved-slots run (comm slots {comm_slots}) {uplo} n={n} nb={nb}: info {info}")
+                ok &= said(p1 > p0 and (x1 > x0) == want_exclusive,
+                           f"reserved-slots run (comm slots {comm_slots}): {p1 - p0} persistent launches, {x1 - x0} with exclusive "
+                           f"compute units (expected {'some' if want_exclusive else 'none'})")
+                diff, norm_a = orig.residual_against(fact)
+                ok &= said(diff / norm_a <= n * oracle.eps_of(np.float64),
+                           f"reserved-slots run (comm slots {comm_slots}) {uplo}: residual {diff / norm_a}")
+                allev = [None] * dist.get_world_size()
+                dist.all_gather_object(allev, (grid.myrow, grid.mycol, [e for e in ev if e[0] != 2]))
+                if rank == 0:
+                    by = {(r, c): e for r, c, e in allev}
+                    for kind, same in ((0, lambda a, b: a[0] == b[0]), (1, lambda a, b: a[1] == b[1])):
+                        for a in by:
+                            for b in by:
+                                if a < b and same(a, b):
+                                    sa = [e for e in by[a] if e[0] == kind]
+                                    sb = [e for e in by[b] if e[0] == kind]
+                                    ok &= said(sa == sb, f"reserved-slots run: communicator members {a} {b} logged different "
+                                                         f"sequences on axis {kind}")
+                orig.close()
+                fact.close()
+            os.environ.pop("DLAF_MI355X_COMM_SLOTS", None)
         # not positive definite: every rank must report the SAME LAPACK info (the reference aborts every rank,
         # src/cusolver/assert_info.cu:35-45, lapack/tile.h:374-378); nobody hangs, nobody returns 0
         # DIST_WORKER_NONSPD_REPEAT: the cases are run that many times (diagnosis of an intermittent failure; default 1)
@@ -397,34 +444,49 @@ def main():
             # hermitian_eigensolver / hermitian_generalized_eigensolver on the grid through the reference's C entries
             # (test_eigensolver.cpp, test_gen_eigensolver.cpp: testEigensolverCorrectness on the gathered results; A and the
             # eigenvector matrix with different source columns)
-            for t, n, nb, src in keep("eig", [("d", 34, 8, 1), ("z", 64, 16, 0), ("s", 32, 5, 1), ("d", 300, 32, 1), ("z", 260, 64, 0),
-                                  ("d", 1100, 256, 1), ("d", 5, 8, 0)]):
+            # the reference's own lists (test/unit/eigensolver/test_eigensolver.cpp:64-76: `sizes` with their
+            # eigensolver_min_band -- the last two are the sub-band cases -- and `sizes_id` on the identity matrix),
+            # the types spread over them, then larger ones
+            ref_sizes = [(0, 2, 100), (5, 8, 100), (34, 34, 100), (4, 3, 100), (16, 10, 100), (34, 13, 100), (32, 5, 100),
+                         (34, 8, 3), (32, 6, 3)]
+            eig_cases = [("sdcz"[i % 4], n, nb, i % 2, b_min, "random") for i, (n, nb, b_min) in enumerate(ref_sizes)]
+            eig_cases += [("d", 34, 8, 1, 3, "random"), ("z", 32, 6, 0, 3, "random")]
+            eig_cases += [(t, n, nb, 1, b_min, "identity") for t in "dz" for n, nb, b_min in [(8, 4, 4), (34, 8, 4)]]
+            eig_cases += [("z", 64, 16, 0, 100, "random"), ("d", 300, 32, 1, 100, "random"), ("z", 260, 64, 0, 100, "random"),
+                          ("d", 1100, 256, 1, 100, "random")]
+            for t, n, nb, src, b_min, kind in keep("eig", eig_cases):
                 dt = oracle.DTYPES[t]
                 sr, sc = (max(0, nprow - 1), min(1, npcol - 1)) if src else (0, 0)
                 zsc = 0 if src else min(1, npcol - 1)
-                a0 = rb.random_hermitian(n, dt, seed=700 + n)
+                dlaf.eigensolver_min_band(b_min)
+                a0 = rb.random_hermitian(n, dt, seed=700 + n) if kind == "random" else np.asfortranarray(np.eye(n, dtype=dt))
                 la = np.asfortranarray(oracle.scatter(a0, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
                 zshape = grid.local_shape(n, nb, sr, zsc)
                 w, lz = dlaf.hermitian_eigensolver(grid, "L", la, nb, sr, sc, n=n, z_jsrc=zsc, z_shape=zshape)
                 z = gather_global(lz, grid, n, nb, sr, zsc, oracle)
+                dlaf.eigensolver_min_band(100)
                 allw = [None] * dist.get_world_size()
                 dist.all_gather_object(allw, w)
                 good = all(np.array_equal(allw[0], x) for x in allw)
-                if rank == 0:
+                if rank == 0 and n > 0:
                     res = td.check_eigensolver(a0, w, z)
                     good &= res["sorted"] and res["orth"] <= res["orth_bar"] and res["residual_ok"]
                     if not good:
-                        print(f"[dist_worker] hermitian_eigensolver FAILED {t} n={n} nb={nb} grid {nprow}x{npcol}: {res}", flush=True)
+                        print(f"[dist_worker] hermitian_eigensolver FAILED {t} n={n} nb={nb} b_min={b_min} {kind} grid {nprow}x{npcol}: {res}", flush=True)
                 ok &= bool(good)
-            for t, n, nb in keep("eig", [("d", 64, 16), ("z", 130, 32)]):
+            # test_gen_eigensolver.cpp:66-72 (the same `sizes`), then two larger ones
+            gen_cases = [("dzsc"[i % 4], n, nb, b_min) for i, (n, nb, b_min) in enumerate(ref_sizes) if n > 0]
+            for t, n, nb, b_min in keep("eig", gen_cases + [("d", 64, 16, 100), ("z", 130, 32, 100)]):
                 dt = oracle.DTYPES[t]
                 sr, sc = max(0, nprow - 1), min(1, npcol - 1)
+                dlaf.eigensolver_min_band(b_min)
                 a0 = rb.random_hermitian(n, dt, seed=900 + n)
                 b0 = rb.random_hermitian(n, dt, seed=901 + n)
                 b0 = np.asfortranarray((b0 @ b0.conj().T / n + 2 * np.eye(n)).astype(dt))
                 la = np.asfortranarray(oracle.scatter(a0, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
                 lb = np.asfortranarray(oracle.scatter(b0, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
                 w, lz = dlaf.hermitian_generalized_eigensolver(grid, "L", la, lb, nb, sr, sc, n=n)
+                dlaf.eigensolver_min_band(100)
                 z = gather_global(lz, grid, n, nb, sr, sc, oracle)
                 if rank == 0:
                     err = td.error_of(dt)

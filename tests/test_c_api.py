@@ -92,6 +92,18 @@ def test_pdpotrf_pzpotrf_from_c_with_mpi(nprow, npcol, order):
     assert r.returncode == 0 and "C_API_TEST OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("nprow,npcol,order", [(1, 1, "R"), (2, 2, "C")])
+def test_pdsyevd_pzheevd_pdsygvd_from_c_with_mpi(nprow, npcol, order):
+    """The eigensolver entries of the reference's C interface from a plain C caller under mpiexec
+    (test/unit/c_api/eigensolver/test_eigensolver_c_api_wrapper.c:17-60): tests/c_api/test_pdsyevd.c."""
+    from conftest import gpu_process_budget
+    gpu_process_budget(nprow * npcol)
+    exe = build("test_pdsyevd")
+    r = run(exe, nprow, npcol, order, 600)
+    assert r.returncode == 0 and "C_API_EIG_TEST OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
 def test_mpi_shim_exports_the_mpi_guarded_declarations():
     """Every prototype inside an #ifdef DLAF_MI355X_WITH_MPI block of include/ is exported by the shim."""
     import re

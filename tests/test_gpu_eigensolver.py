@@ -181,22 +181,87 @@ def random_hermitian(n, dt, seed):
     return np.asfortranarray((a + a.conj().T).astype(dt))
 
 
-# test_eigensolver.cpp: {m, mb} incl. sub-band block sizes
-EIG_SIZES = [(0, 8), (5, 8), (34, 8), (4, 3), (16, 4), (34, 13), (32, 5), (64, 16)]
+# test/unit/eigensolver/test_eigensolver.cpp:64-76 and test_gen_eigensolver.cpp:66-72, verbatim:
+# {m, mb, eigensolver_min_band} -- the last two of `sizes` are the sub-band cases (band 4 at mb = 8, band 3 at mb = 6)
+REF_SIZES = [(0, 2, 100), (5, 8, 100), (34, 34, 100), (4, 3, 100), (16, 10, 100), (34, 13, 100), (32, 5, 100),
+             (34, 8, 3), (32, 6, 3)]
+REF_SIZES_ID = [(8, 4, 4), (34, 8, 4)]   # the identity matrix: full deflation, zero reflectors end to end
 
 
-@pytest.mark.parametrize("t", ["d", "z", "s", "c"])
-def test_hermitian_eigensolver_reference_sizes(dlaf, grid, td, t):
-    dt = DT[t]
-    for n, nb in EIG_SIZES:
-        a0 = random_hermitian(n, dt, 11 + n)
-        a = a0.copy(order="F")
-        a[np.triu_indices(n, 1)] = -9.9
-        w, z = dlaf.hermitian_eigensolver(grid, "L", a, nb)
-        if n == 0:
-            continue
-        res = td.check_eigensolver(a0, w, z)
-        assert res["sorted"] and res["orth"] <= res["orth_bar"] and res["residual_ok"], (t, n, nb, res)
+@pytest.fixture
+def min_band(dlaf):
+    """getTuneParameters().eigensolver_min_band = b_min for one case (test_eigensolver.cpp:142), restored afterwards"""
+    old = dlaf.eigensolver_min_band()
+
+    def set_(b_min):
+        dlaf.eigensolver_min_band(b_min)
+
+    yield set_
+    dlaf.eigensolver_min_band(old)
+
+
+def test_eigensolver_min_band_tune_parameter(dlaf, min_band):
+    """include/dlaf/tune.h:128 + internal/get_band_size.h:18-31; DLAF_EIGENSOLVER_MIN_BAND is read by dlaf_initialize
+    (src/init.cpp:220), checked in a fresh process"""
+    import subprocess
+    import sys
+    assert dlaf.eigensolver_min_band() == 100 and dlaf.get_band_size(512) == 128
+    min_band(3)
+    assert [dlaf.get_band_size(nb) for nb in (8, 6, 34, 512)] == [4, 3, 17, 4]
+    min_band(4)
+    assert [dlaf.get_band_size(nb) for nb in (4, 8)] == [4, 4]
+    code = ("import dla_future_amd as d; d.initialize(); "
+            "print(d.eigensolver_min_band(), d.get_band_size(8), d.get_band_size(512))")
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, DLAF_EIGENSOLVER_MIN_BAND="3"),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.split() == ["3", "4", "4"], (out.stdout, out.stderr[-500:])
+
+
+def test_hermitian_eigensolver_reference_sizes(dlaf, grid, td, min_band):
+    """testEigensolver over exactly the reference's `sizes` (random Hermitian) and `sizes_id` (identity) with their
+    eigensolver_min_band, all four element types (test_eigensolver.cpp:64-76,140-166)"""
+    for t in "sdcz":
+        dt = DT[t]
+        for kind, sizes in (("random", REF_SIZES), ("identity", REF_SIZES_ID)):
+            for n, nb, b_min in sizes:
+                min_band(b_min)
+                a0 = random_hermitian(n, dt, 11 + n) if kind == "random" else np.asfortranarray(np.eye(n, dtype=dt))
+                a = a0.copy(order="F")
+                a[np.triu_indices(n, 1)] = -9.9
+                w, z = dlaf.hermitian_eigensolver(grid, "L", a, nb)
+                if n == 0:
+                    continue
+                res = td.check_eigensolver(a0, w, z)
+                assert res["sorted"] and res["orth"] <= res["orth_bar"] and res["residual_ok"], (t, kind, n, nb, b_min, res)
+                if kind == "identity":
+                    assert np.all(w == 1), (t, n, nb, w)
+
+
+def test_hermitian_generalized_eigensolver_reference_sizes(dlaf, grid, td, min_band):
+    """testGenEigensolver over the reference's `sizes` with their eigensolver_min_band, all four element types, both
+    the plain and the `_factorized` entry (test_gen_eigensolver.cpp:66-72,105-129: B-orthonormality of the
+    eigenvectors and A Z = B Z Lambda)"""
+    for t in "sdcz":
+        dt = DT[t]
+        err = td.error_of(dt)
+        for n, nb, b_min in REF_SIZES:
+            min_band(b_min)
+            a0 = random_hermitian(n, dt, 21 + n)
+            b0 = random_hermitian(n, dt, 22 + n)
+            b0 = np.asfortranarray((b0 @ b0.conj().T / max(n, 1) + np.eye(n, dtype=dt) * 2).astype(dt))
+            a, b = a0.copy(order="F"), b0.copy(order="F")
+            w, z = dlaf.hermitian_generalized_eigensolver(grid, "L", a, b, nb)
+            if n == 0:
+                continue
+            assert np.all(np.diff(w) >= 0)
+            g = z.conj().T @ b0 @ z
+            assert np.abs(g - np.eye(n)).max() <= 10 * n * err * np.abs(b0).max(), (t, n, nb, np.abs(g - np.eye(n)).max())
+            r = a0 @ z - (b0 @ z) * w[None, :]
+            assert np.abs(r).max() <= 10 * n * err * max(1.0, np.abs(a0).max() * np.abs(w).max()), (t, n, nb, np.abs(r).max())
+            w2, z2 = dlaf.hermitian_generalized_eigensolver(grid, "L", a0.copy(order="F"), b, nb, factorized=True)
+            assert np.abs(w2 - w).max() <= 10 * n * err * max(1.0, np.abs(w).max()), (t, n, nb)
 
 
 @pytest.mark.parametrize("t,n,nb", [("d", 1100, 256), ("z", 700, 128), ("d", 2048, 512)])
