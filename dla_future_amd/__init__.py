@@ -23,7 +23,7 @@ from .cholesky import (DeviceMatrix, GeneralDeviceMatrix, Grid, cholesky_factori
 from . import distribution  # noqa: F401
 from .eigensolver import (band_to_tridiagonal, bt_band_to_tridiagonal, bt_reduction_to_band,  # noqa: F401
                           bt_reduction_to_band_device, eigensolver_min_band, eigensolver_profile, get_band_size, hermitian_eigensolver,
-                          hermitian_generalized_eigensolver, red2band_profile, reduction_to_band,
+                          hermitian_generalized_eigensolver, red2band_panel_stats, red2band_profile, reduction_to_band,
                           reduction_to_band_device, tridiagonal_eigensolver)
 
 __all__ = ["band_to_tridiagonal", "bt_band_to_tridiagonal", "eigensolver_profile", "hermitian_eigensolver",

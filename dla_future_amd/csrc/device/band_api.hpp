@@ -108,6 +108,23 @@ template <class T>
 void launch_panel_qr(T* qt, long m, int b, int nr, T* taus, void* scratch, int* info, hipStream_t stream);
 size_t panel_qr_scratch_bytes(int b, size_t elem_size);
 
+// Panel QR, blocked (kernels_hr.hip): the same reflectors from CholeskyQR2 + Householder reconstruction -- three
+// tall-skinny passes on the Cholesky path's kernels instead of b grid-wide exchanges.  These are its small kernels; the
+// sequence is in csrc/host/red2band.cpp (panel_qr_blocked).  `flag` != 0: the panel is not safely positive definite,
+// nothing downstream of the gate writes, the caller falls back to launch_panel_qr.
+bool panel_qr_blocked_supported(int b, long m, int nr, size_t elem_size, bool is_complex);
+// qt[c + r * b] <-> cm[r + c * ld] (m rows, b columns); flag may be null
+template <class T>
+void launch_hr_transpose(T* qt, int b, long m, T* cm, long ld, bool to_cm, const int* flag, hipStream_t stream);
+// raises *flag when max / min of the diagonal of the lower factor l (b x b, ld) exceeds `limit` or is not finite
+template <class T>
+void launch_hr_gate(const T* l, int ld, int b, double limit, int* flag, hipStream_t stream);
+// Householder reconstruction of the top b x b block (see kernels_hr.hip: hr_lu_kernel)
+template <class T>
+void launch_hr_lu(T* q, long ldq, int b, const T* l1, const T* l2, T* lu, T* y1, T* tb, T* taus, const int* flag,
+                  hipStream_t stream);
+void hr_kernels_init();
+
 // panel column block [c0, c0 + b) of tile column jl (tile-local columns cc .. cc + b) <-> transposed panel:
 // qt[c + (g - e0) * b] for the global rows g >= r0 of the local tiles il >= il0 (to_panel) or back (!to_panel)
 template <class T>

@@ -348,6 +348,7 @@ void potrf_kernels_init();
 void potrf_coop_kernels_init();
 void band_kernels_init();
 void bt_kernels_init();
+void hr_kernels_init();
 
 void device_kernels_init() {
   update_kernels_init();
@@ -356,6 +357,7 @@ void device_kernels_init() {
   potrf_coop_kernels_init();
   band_kernels_init();
   bt_kernels_init();
+  hr_kernels_init();
 }
 
 #define INST(T)                                                                \

@@ -507,6 +507,17 @@ void launch_trsm(const TrsmArgs<T>& a, hipStream_t stream) {
                          stream, a, spt);
       return;
     }
+    // the same kernel with 128-column macro blocks for the widths that are whole 128s but not whole 256s (the
+    // tall-skinny solves of the blocked panel factorization of reduction_to_band: n = band = 128)
+    constexpr int NW2 = 128;
+    if (vec && !a.upper && trsm_rows_enabled() && a.nb % 64 == 0 && a.last_rows % 64 == 0 && a.n % NW2 == 0 &&
+        aligned16<T>(a.winv, 0)) {
+      const int spt = a.nb / 64;
+      const long grid = (long) (a.il1 - a.il0) * spt;
+      hipLaunchKernelGGL((trsm_rows_kernel<NW2, 2>), dim3((unsigned) grid), dim3(kThreads), (TrsmRowsCfg<NW2, 2>::LDS_BYTES),
+                         stream, a, spt);
+      return;
+    }
   }
   if constexpr (std::is_same<T, cdouble>::value) {
     constexpr int NW = 128;
@@ -549,6 +560,8 @@ void trsm_kernels_init() {
                              hipFuncAttributeMaxDynamicSharedMemorySize, TrsmRowsZCfg<128, 3>::LDS_BYTES);
   (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_rows_kernel<256, 2>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, TrsmRowsCfg<256, 2>::LDS_BYTES);
+  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_rows_kernel<128, 2>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, TrsmRowsCfg<128, 2>::LDS_BYTES);
   trsm_init_one<float>();
   trsm_init_one<double>();
   trsm_init_one<cfloat>();

@@ -768,6 +768,10 @@ int dlaf_mi355x_eigensolver_profile(double ms[5]) noexcept {
   return 0;
 }
 
+int dlaf_mi355x_red2band_panel_stats(long* blocked, long* fallback) noexcept {
+  red2band_last_panels(blocked, fallback);
+  return 0;
+}
 int dlaf_mi355x_get_eigensolver_min_band(void) noexcept {
   return eigensolver_min_band();
 }

@@ -50,7 +50,15 @@ T scalar(double re) {
 }
 
 double g_last_ms = 0, g_last_flops = 0;
+long g_last_panels[2] = {0, 0};  // panels of the last reduction factored blocked / sent back to the reflector kernel
 }  // namespace
+
+void red2band_last_panels(long* blocked, long* fallback) {
+  if (blocked)
+    *blocked = g_last_panels[0];
+  if (fallback)
+    *fallback = g_last_panels[1];
+}
 
 void red2band_last_profile(double* ms, double* flops) {
   if (ms)
@@ -146,6 +154,27 @@ int reduction_to_band_device(DeviceMatrix<T>& A, int band, T* taus_host) {
   T* part_t = dalloc<T>((size_t) cap_t * nb * (size_t) b);
   void* qr_scratch = nullptr;
   DLAF_HIP_CHECK(hipMalloc(&qr_scratch, panel_qr_scratch_bytes(b, sizeof(T))));
+  // blocked panel factorization (kernels_hr.hip): the panel column-major, two Gram / Cholesky factors, U^T, V1, the
+  // inverted diagonal blocks of the three triangular solves, the flag that sends a panel to the reflector-by-reflector
+  // kernel, the cooperative POTRF's flags
+  const bool blocked_any = panel_qr_blocked_supported(b, std::max<long>(n - b, 0), b, sizeof(T), TypeInfo<T>::is_complex);
+  T *Pcm = nullptr, *hr_g = nullptr, *hr_l2 = nullptr, *hr_lu = nullptr, *hr_y1 = nullptr, *hr_winv = nullptr;
+  int* hr_flag = nullptr;
+  unsigned* hr_sync = nullptr;
+  const size_t hr_wblk = (size_t) ((b + kDiagBlock - 1) / kDiagBlock) * kDiagBlock * kDiagBlock;
+  if (blocked_any) {
+    Pcm = dalloc<T>((size_t) ldp * b);
+    hr_g = dalloc<T>((size_t) b * b);
+    hr_l2 = dalloc<T>((size_t) b * b);
+    hr_lu = dalloc<T>((size_t) b * b);
+    hr_y1 = dalloc<T>((size_t) b * b);
+    hr_winv = dalloc<T>(4 * hr_wblk);
+    DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&hr_flag), sizeof(int)));
+    DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&hr_sync), sizeof(unsigned) * potrf_coop_sync_words(b)));
+  }
+  int* hr_flag_host = nullptr;
+  DLAF_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&hr_flag_host), sizeof(int), hipHostMallocDefault));
+  long panels_blocked = 0, panels_fallback = 0;
 
   hipEvent_t ev0, ev1;
   DLAF_HIP_CHECK(hipEventCreate(&ev0));
@@ -188,6 +217,7 @@ int reduction_to_band_device(DeviceMatrix<T>& A, int band, T* taus_host) {
     const int pcol = cols.owner(J0);
     const bool in_pcol = cols.rank == pcol;
     // ---- 1. the panel, transposed, gathered inside the owning process column ------------------------------------
+    bool panel_t_ready = false;  // the blocked factorization left the T factor in Tm
     if (in_pcol) {
       const long jlp = cols.local_of(J0);
       launch_panel_move(A.tiles, ltr, nb, (int) il0, (int) ltr, (int) jlp, rows.P, rows.shift(), (int) nt,
@@ -200,7 +230,98 @@ int reduction_to_band_device(DeviceMatrix<T>& A, int band, T* taus_host) {
         tr->group_end();
       }
       // ---- 2. reflectors (xGEQR2 without the size-1 reflector) ---------------------------------------------------
-      launch_panel_qr(qt + (size_t) o * b, m, b, nr, taus + c0, qr_scratch, info, s);
+      bool t_ready = false;
+      if constexpr (!TypeInfo<T>::is_complex) {
+        if (blocked_any && panel_qr_blocked_supported(b, m, nr, sizeof(T), false)) {
+          // CholeskyQR2 on the column-major copy, then the Householder reconstruction (kernels_hr.hip).  Every kernel
+          // behind the first factorization looks at hr_flag and does nothing once it is raised.
+          T* P = Pcm;
+          T* qtp = qt + (size_t) o * b;
+          const int nrt = (int) ((m + b - 1) / b);
+          DLAF_HIP_CHECK(hipMemsetAsync(hr_flag, 0, sizeof(int), s));
+          launch_hr_transpose(qtp, b, m, P, ldp, true, nullptr, s);
+          auto gram = [&](T* out) {
+            GemmArgs<T> g;
+            g.M = b;
+            g.N = b;
+            g.K = (int) m;
+            g.a = P;
+            g.lda = ldp;
+            g.opa = 'C';
+            g.b = P;
+            g.ldb = ldp;
+            g.opb = 'N';
+            g.c = out;
+            g.ldc = b;
+            g.alpha = scalar<T>(1.0);
+            g.beta = scalar<T>(0.0);
+            g.ksplit = std::min(ksplit_max, gemm_pick_ksplit<T>(b, b, m));
+            g.partial = gpart;
+            launch_gemm(g, s);
+          };
+          // X L^-T in place on the rows [row0, m) of P (tiles of b rows)
+          auto solve = [&](long row0, const T* L, const T* winv_blocks) {
+            TrsmArgs<T> ta;
+            ta.b = P + row0;
+            ta.b_ts = b;
+            ta.ldb = (int) ldp;
+            ta.il0 = 0;
+            ta.il1 = (int) ((m - row0 + b - 1) / b);
+            ta.pr = 1;
+            ta.ri = 0;
+            ta.nb = b;
+            ta.nt = ta.il1;
+            ta.last_rows = (int) ((m - row0) - (long) (ta.il1 - 1) * b);
+            ta.l = L;
+            ta.ldl = b;
+            ta.winv = winv_blocks;
+            ta.n = b;
+            ta.info = hr_flag;
+            launch_trsm(ta, s);
+          };
+          (void) nrt;
+          gram(hr_g);
+          launch_potrf_coop(hr_g, b, b, hr_winv, hr_flag, 0, hr_sync, s, false, false);
+          // cond(P) >= max / min of the factor's diagonal; CholeskyQR2 is safe far beyond this gate (cond^2 eps << 1)
+          launch_hr_gate(hr_g, b, b, 1.0e4, hr_flag, s);
+          solve(0, hr_g, hr_winv);
+          gram(hr_l2);
+          launch_potrf_coop(hr_l2, b, b, hr_winv + hr_wblk, hr_flag, 0, hr_sync, s, false, false);
+          solve(0, hr_l2, hr_winv + hr_wblk);
+          // reconstruction: top block, V2 = Q2 U^-1, T = -U S V1^-T
+          launch_hr_lu(P, ldp, b, hr_g, hr_l2, hr_lu, hr_y1, Tm, taus + c0, hr_flag, s);
+          launch_invert_diag_blocks(hr_lu, b, b, hr_winv + 2 * hr_wblk, hr_flag, s, false, false);
+          solve(b, hr_lu, hr_winv + 2 * hr_wblk);
+          launch_invert_diag_blocks(hr_y1, b, b, hr_winv + 3 * hr_wblk, hr_flag, s, false, true);
+          {
+            TrsmArgs<T> ta;
+            ta.b = Tm;
+            ta.b_ts = b;
+            ta.ldb = b;
+            ta.il0 = 0;
+            ta.il1 = 1;
+            ta.pr = 1;
+            ta.ri = 0;
+            ta.nb = b;
+            ta.nt = 1;
+            ta.last_rows = b;
+            ta.l = hr_y1;
+            ta.ldl = b;
+            ta.winv = hr_winv + 3 * hr_wblk;
+            ta.n = b;
+            ta.info = hr_flag;
+            launch_trsm(ta, s);
+          }
+          launch_hr_transpose(qtp, b, m, P, ldp, false, hr_flag, s);
+          DLAF_HIP_CHECK(hipMemcpyAsync(hr_flag_host, hr_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+          DLAF_HIP_CHECK(hipStreamSynchronize(s));
+          t_ready = (*hr_flag_host == 0);
+          ++(t_ready ? panels_blocked : panels_fallback);
+        }
+      }
+      if (!t_ready)
+        launch_panel_qr(qt + (size_t) o * b, m, b, nr, taus + c0, qr_scratch, info, s);
+      panel_t_ready = t_ready;
       launch_panel_move(A.tiles, ltr, nb, (int) il0, (int) ltr, (int) jlp, rows.P, rows.shift(), (int) nt,
                         rows.last_extent(), cc, b, qt, e0, r0, false, s);
     }
@@ -210,7 +331,9 @@ int reduction_to_band_device(DeviceMatrix<T>& A, int band, T* taus_host) {
     }
     // ---- 3. well-formed V, T factor, W = V T  (every rank, from the replicated panel) ------------------------
     launch_make_v(qt, b, nr, e0, r0, n, V, ldp, s);
-    {
+    // (the blocked factorization delivers T = -U S V1^-T with the reflectors; on a grid with several process columns
+    // the ranks outside the panel's column have only the reflectors, and every rank forms T the same way)
+    if (!(panel_t_ready && cols.P == 1)) {
       GemmArgs<T> g;
       g.M = b;
       g.N = b;
@@ -228,9 +351,9 @@ int reduction_to_band_device(DeviceMatrix<T>& A, int band, T* taus_host) {
       g.ksplit = std::min(ksplit_max, gemm_pick_ksplit<T>(b, b, me));
       g.partial = gpart;
       launch_gemm(g, s);
+      DLAF_HIP_CHECK(hipMemsetAsync(Tm, 0, (size_t) b * b * sizeof(T), s));
+      launch_tfactor(S, (long) b, taus + c0, nr, Tm, (long) b, s);
     }
-    DLAF_HIP_CHECK(hipMemsetAsync(Tm, 0, (size_t) b * b * sizeof(T), s));
-    launch_tfactor(S, (long) b, taus + c0, nr, Tm, (long) b, s);
     {
       GemmArgs<T> g;
       g.M = (int) me;
@@ -396,6 +519,15 @@ int reduction_to_band_device(DeviceMatrix<T>& A, int band, T* taus_host) {
   for (T* q : {qt, Vb[0], Vb[1], W, Xb[0], Xb[1], S, Tm, W2, taus, gpart, part_s, part_t})
     DLAF_HIP_CHECK(hipFree(q));
   DLAF_HIP_CHECK(hipFree(qr_scratch));
+  if (blocked_any) {
+    for (T* q : {Pcm, hr_g, hr_l2, hr_lu, hr_y1, hr_winv})
+      DLAF_HIP_CHECK(hipFree(q));
+    DLAF_HIP_CHECK(hipFree(hr_flag));
+    DLAF_HIP_CHECK(hipFree(hr_sync));
+  }
+  DLAF_HIP_CHECK(hipHostFree(hr_flag_host));
+  g_last_panels[0] = panels_blocked;
+  g_last_panels[1] = panels_fallback;
   if (h_info == kInfoSchedulingFailure)
     fatal("[dlaf_mi355x] reduction_to_band: the cooperative panel kernel could not make progress (its workgroups were "
           "not co-resident)\n");

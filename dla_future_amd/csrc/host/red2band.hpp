@@ -15,6 +15,9 @@ inline T make_host_el(double re) {
 
 // eigensolver/internal/get_band_size.h:20-31 with the tune parameter eigensolver_min_band (tune.h:128, default 100)
 int get_band_size(int nb);
+// panels of this process's last reduction_to_band that took the blocked factorization (CholeskyQR2 + Householder
+// reconstruction) / that it handed back to the reflector-by-reflector kernel
+void red2band_last_panels(long* blocked, long* fallback);
 int eigensolver_min_band();
 void set_eigensolver_min_band(int b_min);
 

@@ -18,6 +18,14 @@ def get_band_size(nb: int) -> int:
     return lib().dlaf_mi355x_get_band_size(nb)
 
 
+def red2band_panel_stats():
+    """(blocked, fallback): panels of this process's last reduction_to_band factored by the blocked path / handed back to
+    the reflector-by-reflector kernel."""
+    a, b = C.c_long(0), C.c_long(0)
+    lib().dlaf_mi355x_red2band_panel_stats(C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
 def eigensolver_min_band(b_min: int | None = None) -> int:
     """getTuneParameters().eigensolver_min_band (include/dlaf/tune.h:128; DLAF_EIGENSOLVER_MIN_BAND, src/init.cpp:220):
     returns the current value, after setting it when `b_min` is given."""

@@ -242,6 +242,9 @@ DLAF_EXTERN_C int dlaf_mi355x_bt_reduction_to_band_c(int context, int band_size,
 DLAF_EXTERN_C int dlaf_mi355x_bt_reduction_to_band_z(int context, int band_size, dlaf_complex_z* c,
                                                      struct DLAF_descriptor descc, const dlaf_complex_z* v,
                                                      struct DLAF_descriptor descv, const dlaf_complex_z* taus) DLAF_NOEXCEPT;
+/* Panels of this process's last reduction_to_band factored by the blocked path (CholeskyQR2 + Householder
+ * reconstruction, csrc/device/kernels_hr.hip) / handed back to the reflector-by-reflector kernel by its gate. */
+DLAF_EXTERN_C int dlaf_mi355x_red2band_panel_stats(long* blocked, long* fallback) DLAF_NOEXCEPT;
 /* Tune parameter eigensolver_min_band (include/dlaf/tune.h:71-75,128; default 100).  dlaf_initialize reads
  * DLAF_EIGENSOLVER_MIN_BAND and --dlaf:eigensolver-min-band like src/init.cpp:220; the setter is what the reference's
  * tests do with getTuneParameters().eigensolver_min_band (test/unit/eigensolver/test_eigensolver.cpp:142). b_min >= 2. */

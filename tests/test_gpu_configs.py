@@ -239,7 +239,8 @@ def test_tile_herk_fast_path_shapes(dlaf, oracle, t, n, k):
 
 
 @pytest.mark.parametrize("t,m,n", [("d", 512, 512), ("z", 512, 512), ("d", 1024, 1024), ("z", 1024, 1024), ("s", 512, 512),
-                                   ("c", 512, 512), ("d", 1024, 1000), ("d", 1000, 1024), ("z", 384, 520)])
+                                   ("c", 512, 512), ("d", 1024, 1000), ("d", 1000, 1024), ("z", 384, 520),
+                                   ("d", 256, 128), ("d", 640, 384)])   # (widths of whole 128s: the 128-column macro block)
 def test_tile_trsm_fast_path_shapes(dlaf, oracle, t, m, n):
     """Whole 128-row strips and 64-column blocks of a full panel tile (test_trsm.h:35-62 argument sets)."""
     rng = np.random.default_rng(17)

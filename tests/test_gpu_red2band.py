@@ -84,6 +84,37 @@ def test_reduction_to_band_fast_path_sizes(dlaf, grid, rb, oracle, t, n, nb, ban
     assert np.abs(ev0 - ev1).max() <= n * n * rb.error_of(dt)
 
 
+def test_reduction_to_band_blocked_panels_and_their_gate(dlaf, grid, rb, oracle):
+    """fp64 panels of band 64 / 128 take the blocked factorization (CholeskyQR2 + Householder reconstruction,
+    csrc/device/kernels_hr.hip) and must give xGEQR2's reflectors, taus and R element by element (run_and_check compares
+    with the oracle's reflector-by-reflector restatement); panels whose Gram matrix is singular or badly conditioned are
+    handed back to the reflector-by-reflector kernel by the gate -- same checks."""
+    for n, nb, band in [(2048, 512, 128), (1100, 256, 128), (700, 128, 64)]:
+        run_and_check(dlaf, grid, rb, oracle, "d", n, nb, band, False)
+        blocked, fallback = dlaf.red2band_panel_stats()
+        assert blocked > 0 and fallback == 0, (n, nb, band, blocked, fallback)
+    # the identity matrix: every panel is zero below the band (test_eigensolver.cpp:72-76 runs it end to end)
+    n, nb, band = 1024, 256, 128
+    a = np.asfortranarray(np.eye(n))
+    taus = dlaf.reduction_to_band(grid, a, nb, band)
+    blocked, fallback = dlaf.red2band_panel_stats()
+    assert blocked == 0 and fallback > 0, (blocked, fallback)
+    assert np.array_equal(a, np.eye(n)) and not taus.any()
+    # two columns of every panel agree to 1e-9: cond ~ 1e9, far beyond what CholeskyQR2 may be trusted with
+    dt = np.float64
+    a0 = rb.random_hermitian(n, dt, seed=77)
+    for c in range(0, n - 1, band):
+        a0[:, c + 1] = a0[:, c] * (1 + 1e-9)
+        a0[c + 1, :] = a0[:, c + 1]
+    a0 = np.asfortranarray((a0 + a0.T) / 2)
+    a = a0.copy(order="F")
+    taus = dlaf.reduction_to_band(grid, a, nb, band)
+    blocked, fallback = dlaf.red2band_panel_stats()
+    assert fallback > 0, (blocked, fallback)
+    ok, diff, tol = rb.check_result(a0, a, taus, band)
+    assert ok, (diff, tol)
+
+
 def test_band_size_rule(dlaf):
     # get_band_size.h:20-31
     assert [dlaf.get_band_size(nb) for nb in (512, 1024, 256, 64, 100, 200, 300)] == [128, 128, 128, 64, 100, 100, 100]
