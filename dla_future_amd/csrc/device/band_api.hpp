@@ -116,13 +116,13 @@ bool panel_qr_blocked_supported(int b, long m, int nr, size_t elem_size, bool is
 // qt[c + r * b] <-> cm[r + c * ld] (m rows, b columns); flag may be null
 template <class T>
 void launch_hr_transpose(T* qt, int b, long m, T* cm, long ld, bool to_cm, const int* flag, hipStream_t stream);
-// raises *flag when max / min of the diagonal of the lower factor l (b x b, ld) exceeds `limit` or is not finite
+// raises *flag when max / min of the diagonal of the lower factor l (b x b, ld) exceeds `limit` (<= 0: no gate) or is
+// not finite; zeroes the strict upper triangle of l
 template <class T>
-void launch_hr_gate(const T* l, int ld, int b, double limit, int* flag, hipStream_t stream);
-// Householder reconstruction of the top b x b block (see kernels_hr.hip: hr_lu_kernel)
+void launch_hr_gate(T* l, int ld, int b, double limit, int* flag, hipStream_t stream);
+// Householder reconstruction of the top b x b block from it and R = L2^T L1^T (see kernels_hr.hip: hr_lu_kernel)
 template <class T>
-void launch_hr_lu(T* q, long ldq, int b, const T* l1, const T* l2, T* lu, T* y1, T* tb, T* taus, const int* flag,
-                  hipStream_t stream);
+void launch_hr_lu(T* q, long ldq, int b, const T* rmat, T* lu, T* y1, T* tb, T* taus, const int* flag, hipStream_t stream);
 void hr_kernels_init();
 
 // panel column block [c0, c0 + b) of tile column jl (tile-local columns cc .. cc + b) <-> transposed panel:

@@ -933,9 +933,16 @@ template <class T>
 int gemm_pick_ksplit(int M, int N, long K) {
   using Cfg = typename GenCfg<T>::type;
   const long blocks = (long) ((M + Cfg::BM - 1) / Cfg::BM) * ((N + Cfg::BN - 1) / Cfg::BN);
-  if (blocks >= 256 || K < 4 * 512)
+  // shortest K chunk of a split product (DLAF_MI355X_GEMM_KCHUNK): 512 left the tall-skinny b x b products of
+  // reduction_to_band (b = 128: two output blocks) on 80 of the 256 compute units at K = 20480:
+  // 85 us per Gram matrix, 44 us with 256, 40 with 128 -- profiles/r04_red2band_*
+  static const long kmin = [] {
+    const char* e = std::getenv("DLAF_MI355X_GEMM_KCHUNK");
+    return e ? std::max(64L, std::atol(e)) : 128L;
+  }();
+  if (blocks >= 256 || K < 4 * kmin)
     return 1;
-  long ks = std::min<long>((512 + blocks - 1) / blocks, K / 512);
+  long ks = std::min<long>((1024 + blocks - 1) / blocks, K / kmin);
   return (int) std::max<long>(1, std::min<long>(ks, 256));
 }
 

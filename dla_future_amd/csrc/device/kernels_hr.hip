@@ -69,11 +69,19 @@ __global__ __launch_bounds__(256) void hr_transpose_kernel(T* qt, int b, long m,
 
 // The gate between the first Cholesky factorization and everything built on it: the diagonal of the factor L of
 // G = P^T P bounds the condition number of P from below (max / min of |l_jj|); CholeskyQR2 delivers a Q that is
-// orthonormal to rounding while cond(P)^2 eps << 1.  Beyond `limit`, or for a factor that is not finite, the flag is
-// raised.  One wave.
+// orthonormal to rounding while cond(P)^2 eps << 1.  Beyond `limit` (<= 0: no gate), or for a factor that is not
+// finite, the flag is raised.  The strict upper triangle of l -- which the factorization leaves as it found it -- is
+// zeroed, so that R = L2^T L1^T can be formed by the general product.  One workgroup.
 template <class T>
-__global__ __launch_bounds__(64) void hr_gate_kernel(const T* l, int ld, int b, T limit, int* flag) {
+__global__ __launch_bounds__(256) void hr_gate_kernel(T* l, int ld, int b, T limit, int* flag) {
   if (*flag != 0)
+    return;
+  for (int idx = threadIdx.x; idx < b * b; idx += 256) {
+    const int r = idx % b, c = idx / b;
+    if (r < c)
+      l[r + (long) c * ld] = T(0);
+  }
+  if (threadIdx.x >= 64)
     return;
   T mx = 0, mn = 0;
   bool bad = false, first = true;
@@ -95,110 +103,106 @@ __global__ __launch_bounds__(64) void hr_gate_kernel(const T* l, int ld, int b, 
     }
     bad = bad || (__shfl_xor(bad ? 1 : 0, off) != 0);
   }
-  if (threadIdx.x == 0 && (bad || !(mx <= limit * mn)))
+  if (threadIdx.x == 0 && (bad || (limit > T(0) && !(mx <= limit * mn))))
     atomicCAS(flag, 0, 1);
 }
 
-// One workgroup of NT threads.  In: the top b x b block of Q (column-major, ldq), the two Cholesky factors L1, L2
-// (lower, ld b: G = L1 L1^T, G2 = L2 L2^T).  Out:
-//   top block of Q  <-  xGEQR2's output: S R on and above the diagonal (R = L2^T L1^T), V1 strictly below it
+// One workgroup of NT threads.  In: the top b x b block of Q (column-major, ldq), R = L2^T L1^T (b x b, ld b, upper).
+// Out:
+//   top block of Q  <-  xGEQR2's output: S R on and above the diagonal, V1 strictly below it
 //   lu   (b x b, ld b, lower)  = U^T: the solve of the rows below, V2 = Q2 U^-1, runs as X (U^T)^T = Q2 on the panel TRSM
 //   y1   (b x b, ld b, lower, unit diagonal stored)  = V1
 //   tb   (b x b, ld b, upper, strict lower part zero) = -U S: T = tb V1^-T by one more TRSM
 //   taus[j] = -u_jj s_j
-// The elimination keeps W = Q1 in LDS ([row][col], stride b + 1) and writes NOTHING into row j / column j during
-// step j (the column is scaled at the end, every thread forms the pivot u_jj = w_jj - s_j for itself): one barrier per
-// step, b steps.
-template <class T, int NT>
-__global__ __launch_bounds__(NT) void hr_lu_kernel(T* q, long ldq, int b, const T* l1, const T* l2, T* lu, T* y1, T* tb, T* taus,
+// The elimination keeps W = Q1 in REGISTERS: thread (column c = t % b, row group g = t / b) holds the rows g + G k of
+// its column (G = NT / b row groups, b / G rows each).  Step j needs column j (the multipliers, unscaled) and row j of
+// the current matrix: their owners put them into two small LDS vectors right after they have updated them in step
+// j - 1 (double-buffered), so a step is ONE barrier, b / G + 1 broadcast reads and as many fused multiply-adds.
+// Nothing is written into row j / column j during or after step j: the column is scaled at the end, and every thread
+// forms the pivot u_jj = w_jj - s_j for itself.
+template <class T, int NT, int RPT>
+__global__ __launch_bounds__(NT) void hr_lu_kernel(T* q, long ldq, int b, const T* rmat, T* lu, T* y1, T* tb, T* taus,
                                                    const int* flag) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  T* w = reinterpret_cast<T*>(lds_raw);  // [b][b + 1]
-  T* sg = w + (size_t) b * (b + 1);      // [b] signs
-  T* pv = sg + b;                        // [b] pivots u_jj
+  __shared__ T colbuf[2][128];
+  __shared__ T rowbuf[2][128];
+  __shared__ T sg[128];
+  __shared__ T pv[128];
   if (*flag != 0)
     return;
   const int t = threadIdx.x;
-  const int st = b + 1;
-  for (int idx = t; idx < b * b; idx += NT) {
-    const int r = idx % b, c = idx / b;
-    w[r * st + c] = q[r + (long) c * ldq];
-  }
-  __syncthreads();
-  // ---- R = L2^T L1^T, rows scaled by S later: kept in registers until the signs are known --------------------------
-  // element e = t + k NT of the upper triangle enumeration (j <= c), column-major over c
-  constexpr int kMaxPer = 16;  // b <= 128 with NT = 1024: 8256 / 1024 -> 9
-  T racc[kMaxPer];
-  const int nup = b * (b + 1) / 2;
+  const int c = t % b, g = t / b, G = NT / b;  // (RPT == b / G)
+  T w[RPT];
 #pragma unroll
-  for (int k = 0; k < kMaxPer; ++k) {
-    racc[k] = 0;
-    const int e = t + k * NT;
-    if (e < nup) {
-      // e -> (j, c), j <= c: c = largest with c (c + 1) / 2 <= e
-      int c = (int) ((sqrtf(8.0f * (float) e + 1.0f) - 1.0f) * 0.5f);
-      while ((c + 1) * (c + 2) / 2 <= e)
-        ++c;
-      while (c * (c + 1) / 2 > e)
-        --c;
-      const int j = e - c * (c + 1) / 2;
-      T acc = 0;
-      for (int kk = j; kk <= c; ++kk)
-        acc += l2[kk + (long) j * b] * l1[c + (long) kk * b];
-      racc[k] = acc;
-    }
+  for (int k = 0; k < RPT; ++k)
+    w[k] = q[(g + G * k) + (long) c * ldq];
+  if (c == 0) {
+#pragma unroll
+    for (int k = 0; k < RPT; ++k)
+      colbuf[0][g + G * k] = w[k];
   }
-  // ---- elimination --------------------------------------------------------------------------------------------------
-  const int c_own = t % b;          // (b a power of two or not: the mapping only needs NT >= b)
-  const int r_first = t / b, r_step = NT / b;
+  if (g == 0)
+    rowbuf[0][c] = w[0];
+  __syncthreads();
   for (int j = 0; j < b; ++j) {
-    const T wjj = w[j * st + j];
+    const int par = j & 1;
+    const T wjj = rowbuf[par][j];
     const T s = (wjj >= T(0)) ? T(-1) : T(1);
     const T piv = wjj - s;
-    if (c_own > j) {
-      const T u = w[j * st + c_own] / piv;  // (u_jc / u_jj: one division per thread and step)
-      for (int r = j + 1 + r_first; r < b; r += r_step)
-        w[r * st + c_own] -= w[r * st + j] * u;
-    }
     if (t == 0) {
       sg[j] = s;
       pv[j] = piv;
     }
+    {
+      // branch-free: all the multipliers of the thread's rows are read at once (independent broadcast reads: one LDS
+      // latency per step, not one per row), rows and columns that are done take a zero factor
+      const T u = (c > j) ? rowbuf[par][c] / piv : T(0);  // u_jc / u_jj
+      T l[RPT];
+#pragma unroll
+      for (int k = 0; k < RPT; ++k)
+        l[k] = colbuf[par][g + G * k];
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        const T lm = (g + G * k > j) ? l[k] : T(0);
+        w[k] = __builtin_fma(-lm, u, w[k]);
+      }
+    }
+    // hand column j + 1 and row j + 1 to the next step
+    const int jn = j + 1;
+    if (jn < b) {
+      if (c == jn) {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k)
+          colbuf[par ^ 1][g + G * k] = w[k];
+      }
+      if (g == jn % G) {
+        const int kn = jn / G;
+        T v = w[0];
+#pragma unroll
+        for (int k = 1; k < RPT; ++k)
+          v = (k == kn) ? w[k] : v;
+        rowbuf[par ^ 1][c] = v;
+      }
+    }
     __syncthreads();
   }
   // ---- outputs ----------------------------------------------------------------------------------------------------------
-  for (int idx = t; idx < b * b; idx += NT) {
-    const int r = idx % b, c = idx / b;
+  const T pc = pv[c], sc = sg[c];
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    const int r = g + G * k;
     T yv = 0, uv = 0;
     if (r > c)
-      yv = w[r * st + c] / pv[c];          // V1, strictly lower
+      yv = w[k] / pc;  // V1, strictly lower
     else if (r == c)
-      uv = pv[c];
+      uv = pc;
     else
-      uv = w[r * st + c];                  // U, strictly upper
-    // y1: lower with the unit diagonal stored
+      uv = w[k];       // U, strictly upper
     y1[r + (long) c * b] = r > c ? yv : (r == c ? T(1) : T(0));
-    // lu = U^T: element (c, r) of lu is u_rc
-    lu[c + (long) r * b] = r <= c ? uv : T(0);
-    // tb = -U S: column c scaled by s_c
-    tb[r + (long) c * b] = r <= c ? -uv * sg[c] : T(0);
-    if (r > c)
-      q[r + (long) c * ldq] = yv;
+    lu[c + (long) r * b] = r <= c ? uv : T(0);          // element (c, r) of U^T
+    tb[r + (long) c * b] = r <= c ? -uv * sc : T(0);    // -U S: column c scaled by s_c
+    q[r + (long) c * ldq] = r > c ? yv : sg[r] * rmat[r + (long) c * b];
     if (r == c)
-      taus[c] = -pv[c] * sg[c];
-  }
-#pragma unroll
-  for (int k = 0; k < kMaxPer; ++k) {
-    const int e = t + k * NT;
-    if (e < nup) {
-      int c = (int) ((sqrtf(8.0f * (float) e + 1.0f) - 1.0f) * 0.5f);
-      while ((c + 1) * (c + 2) / 2 <= e)
-        ++c;
-      while (c * (c + 1) / 2 > e)
-        --c;
-      const int j = e - c * (c + 1) / 2;
-      q[j + (long) c * ldq] = sg[j] * racc[k];
-    }
+      taus[c] = -pc * sc;
   }
 }
 
@@ -211,7 +215,7 @@ bool panel_qr_blocked_supported(int b, long m, int nr, size_t elem_size, bool is
   }();
   // fp64 panels with whole 64-column blocks, a full set of reflectors and at least 2 b rows; everything else
   // (complex and single precision, the last panels of a matrix, narrow bands) keeps the reflector-by-reflector kernel
-  return on && !is_complex && elem_size == 8 && b >= 64 && b <= 128 && b % 64 == 0 && nr == b && m >= 2L * b;
+  return on && !is_complex && elem_size == 8 && (b == 64 || b == 128) && nr == b && m >= 2L * b;
 }
 
 template <class T>
@@ -223,33 +227,29 @@ void launch_hr_transpose(T* qt, int b, long m, T* cm, long ld, bool to_cm, const
 }
 
 template <class T>
-void launch_hr_gate(const T* l, int ld, int b, double limit, int* flag, hipStream_t stream) {
-  hipLaunchKernelGGL((hr_gate_kernel<T>), dim3(1), dim3(64), 0, stream, l, ld, b, (T) limit, flag);
+void launch_hr_gate(T* l, int ld, int b, double limit, int* flag, hipStream_t stream) {
+  hipLaunchKernelGGL((hr_gate_kernel<T>), dim3(1), dim3(256), 0, stream, l, ld, b, (T) limit, flag);
 }
 
 template <class T>
-void launch_hr_lu(T* q, long ldq, int b, const T* l1, const T* l2, T* lu, T* y1, T* tb, T* taus, const int* flag,
-                  hipStream_t stream) {
+void launch_hr_lu(T* q, long ldq, int b, const T* rmat, T* lu, T* y1, T* tb, T* taus, const int* flag, hipStream_t stream) {
   constexpr int NT = 1024;
-  const size_t lds = ((size_t) b * (b + 1) + 2 * (size_t) b) * sizeof(T);
-  if (b > 128 || lds > 150 * 1024) {
+  if (b == 128)
+    hipLaunchKernelGGL((hr_lu_kernel<T, NT, 16>), dim3(1), dim3(NT), 0, stream, q, ldq, b, rmat, lu, y1, tb, taus, flag);
+  else if (b == 64)
+    hipLaunchKernelGGL((hr_lu_kernel<T, NT, 4>), dim3(1), dim3(NT), 0, stream, q, ldq, b, rmat, lu, y1, tb, taus, flag);
+  else {
     fprintf(stderr, "[dlaf_mi355x] Householder reconstruction: band %d is not supported\n", b);
     abort();
   }
-  hipLaunchKernelGGL((hr_lu_kernel<T, NT>), dim3(1), dim3(NT), lds, stream, q, ldq, b, l1, l2, lu, y1, tb, taus, flag);
 }
 
-void hr_kernels_init() {
-  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_lu_kernel<double, 1024>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&hr_lu_kernel<float, 1024>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-}
+void hr_kernels_init() {}
 
 #define INST(T)                                                                                            \
   template void launch_hr_transpose<T>(T*, int, long, T*, long, bool, const int*, hipStream_t);            \
-  template void launch_hr_gate<T>(const T*, int, int, double, int*, hipStream_t);                          \
-  template void launch_hr_lu<T>(T*, long, int, const T*, const T*, T*, T*, T*, T*, const int*, hipStream_t);
+  template void launch_hr_gate<T>(T*, int, int, double, int*, hipStream_t);                                \
+  template void launch_hr_lu<T>(T*, long, int, const T*, T*, T*, T*, T*, const int*, hipStream_t);
 INST(float)
 INST(double)
 #undef INST

@@ -158,7 +158,7 @@ int reduction_to_band_device(DeviceMatrix<T>& A, int band, T* taus_host) {
   // inverted diagonal blocks of the three triangular solves, the flag that sends a panel to the reflector-by-reflector
   // kernel, the cooperative POTRF's flags
   const bool blocked_any = panel_qr_blocked_supported(b, std::max<long>(n - b, 0), b, sizeof(T), TypeInfo<T>::is_complex);
-  T *Pcm = nullptr, *hr_g = nullptr, *hr_l2 = nullptr, *hr_lu = nullptr, *hr_y1 = nullptr, *hr_winv = nullptr;
+  T *Pcm = nullptr, *hr_g = nullptr, *hr_l2 = nullptr, *hr_r = nullptr, *hr_lu = nullptr, *hr_y1 = nullptr, *hr_winv = nullptr;
   int* hr_flag = nullptr;
   unsigned* hr_sync = nullptr;
   const size_t hr_wblk = (size_t) ((b + kDiagBlock - 1) / kDiagBlock) * kDiagBlock * kDiagBlock;
@@ -166,6 +166,7 @@ int reduction_to_band_device(DeviceMatrix<T>& A, int band, T* taus_host) {
     Pcm = dalloc<T>((size_t) ldp * b);
     hr_g = dalloc<T>((size_t) b * b);
     hr_l2 = dalloc<T>((size_t) b * b);
+    hr_r = dalloc<T>((size_t) b * b);
     hr_lu = dalloc<T>((size_t) b * b);
     hr_y1 = dalloc<T>((size_t) b * b);
     hr_winv = dalloc<T>(4 * hr_wblk);
@@ -287,9 +288,27 @@ int reduction_to_band_device(DeviceMatrix<T>& A, int band, T* taus_host) {
           solve(0, hr_g, hr_winv);
           gram(hr_l2);
           launch_potrf_coop(hr_l2, b, b, hr_winv + hr_wblk, hr_flag, 0, hr_sync, s, false, false);
+          launch_hr_gate(hr_l2, b, b, 0.0, hr_flag, s);  // (no gate: zeroes the strict upper triangle)
           solve(0, hr_l2, hr_winv + hr_wblk);
+          {
+            GemmArgs<T> g;  // R = L2^T L1^T
+            g.M = b;
+            g.N = b;
+            g.K = b;
+            g.a = hr_l2;
+            g.lda = b;
+            g.opa = 'C';
+            g.b = hr_g;
+            g.ldb = b;
+            g.opb = 'C';
+            g.c = hr_r;
+            g.ldc = b;
+            g.alpha = scalar<T>(1.0);
+            g.beta = scalar<T>(0.0);
+            launch_gemm(g, s);
+          }
           // reconstruction: top block, V2 = Q2 U^-1, T = -U S V1^-T
-          launch_hr_lu(P, ldp, b, hr_g, hr_l2, hr_lu, hr_y1, Tm, taus + c0, hr_flag, s);
+          launch_hr_lu(P, ldp, b, hr_r, hr_lu, hr_y1, Tm, taus + c0, hr_flag, s);
           launch_invert_diag_blocks(hr_lu, b, b, hr_winv + 2 * hr_wblk, hr_flag, s, false, false);
           solve(b, hr_lu, hr_winv + 2 * hr_wblk);
           launch_invert_diag_blocks(hr_y1, b, b, hr_winv + 3 * hr_wblk, hr_flag, s, false, true);
@@ -520,7 +539,7 @@ int reduction_to_band_device(DeviceMatrix<T>& A, int band, T* taus_host) {
     DLAF_HIP_CHECK(hipFree(q));
   DLAF_HIP_CHECK(hipFree(qr_scratch));
   if (blocked_any) {
-    for (T* q : {Pcm, hr_g, hr_l2, hr_lu, hr_y1, hr_winv})
+    for (T* q : {Pcm, hr_g, hr_l2, hr_r, hr_lu, hr_y1, hr_winv})
       DLAF_HIP_CHECK(hipFree(q));
     DLAF_HIP_CHECK(hipFree(hr_flag));
     DLAF_HIP_CHECK(hipFree(hr_sync));
