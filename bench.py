@@ -111,7 +111,7 @@ def red2band_line(dlaf, grid, n, nb, runs=2):
             "fraction_of_fp64_mfma_peak": round(tf / PEAK_FP64_MFMA_TFLOPS, 4)}
 
 
-def eigensolver_line(dlaf, grid, n, nb, runs=1):
+def eigensolver_line(dlaf, grid, n, nb, runs=2):
     """BASELINE configs[4] on one GPU: the whole Hermitian eigensolver (reduction_to_band, band_to_tridiagonal,
     tridiagonal_eigensolver, bt_band_to_tridiagonal, bt_reduction_to_band; eigensolver/impl.h:38-55) through the
     reference's C entry dlaf_symmetric_eigensolver_d on a random symmetric matrix.  Reported: the sum of the per-stage

@@ -131,6 +131,8 @@ __global__ __launch_bounds__(NT) void hr_lu_kernel(T* q, long ldq, int b, const 
     return;
   const int t = threadIdx.x;
   const int c = t % b, g = t / b, G = NT / b;  // (RPT == b / G)
+  const int gs = __builtin_amdgcn_readfirstlane(g);                          // wave-uniform copies
+  const int cmax = __builtin_amdgcn_readfirstlane(((t & ~63) % b) + 63);    // highest column of this wave
   T w[RPT];
 #pragma unroll
   for (int k = 0; k < RPT; ++k)
@@ -152,19 +154,21 @@ __global__ __launch_bounds__(NT) void hr_lu_kernel(T* q, long ldq, int b, const 
       sg[j] = s;
       pv[j] = piv;
     }
-    {
-      // branch-free: all the multipliers of the thread's rows are read at once (independent broadcast reads: one LDS
-      // latency per step, not one per row), rows and columns that are done take a zero factor
+    // rows g + G k <= j and columns <= j are done.  Both tests are made WAVE-UNIFORM (a wave's 64 consecutive threads
+    // share the row group, b >= 64, and a wave whose highest column is done has nothing to do at all), so they are
+    // scalar branches around the reads and multiply-adds instead of per-lane selects on every element
+    if (cmax > j) {
       const T u = (c > j) ? rowbuf[par][c] / piv : T(0);  // u_jc / u_jj
+      const int k0 = (j >= gs) ? (j - gs) / G + 1 : 0;    // first row index of the thread that is still active
       T l[RPT];
 #pragma unroll
       for (int k = 0; k < RPT; ++k)
-        l[k] = colbuf[par][g + G * k];
+        if (k >= k0)
+          l[k] = colbuf[par][gs + G * k];
 #pragma unroll
-      for (int k = 0; k < RPT; ++k) {
-        const T lm = (g + G * k > j) ? l[k] : T(0);
-        w[k] = __builtin_fma(-lm, u, w[k]);
-      }
+      for (int k = 0; k < RPT; ++k)
+        if (k >= k0)
+          w[k] = __builtin_fma(-l[k], u, w[k]);
     }
     // hand column j + 1 and row j + 1 to the next step
     const int jn = j + 1;

@@ -35,7 +35,7 @@ namespace {
 template <class T>
 T* ealloc(size_t elems) {
   T* p = nullptr;
-  DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(elems, 1) * sizeof(T)));
+  DLAF_HIP_CHECK(pool_malloc(reinterpret_cast<void**>(&p), std::max<size_t>(elems, 1) * sizeof(T)));
   return p;
 }
 double g_stage_ms[5] = {0, 0, 0, 0, 0};
@@ -117,8 +117,8 @@ int band_to_tridiag_device(DeviceMatrix<T>& A, int band, real_t<T>* d, real_t<T>
   int h_info = 0;
   DLAF_HIP_CHECK(hipMemcpyAsync(&h_info, A.info, sizeof(int), hipMemcpyDeviceToHost, s));
   g_stage_ms[1] = timer.stop();
-  DLAF_HIP_CHECK(hipFree(bandm));
-  DLAF_HIP_CHECK(hipFree(sync));
+  DLAF_HIP_CHECK(pool_free(bandm));
+  DLAF_HIP_CHECK(pool_free(sync));
   if (h_info == kInfoSchedulingFailure)
     fatal("[dlaf_mi355x] band_to_tridiagonal: a sweep gave up waiting for its predecessor (the workgroup that owns it "
           "made no progress)\n");
@@ -142,9 +142,9 @@ int band_to_tridiag_host(Grid* g, const T* a, long lda, long n, int nb, int isrc
     DLAF_HIP_CHECK(hipMemcpy2D(v, (size_t) ldv * sizeof(T), dv, (size_t) n * sizeof(T), (size_t) n * sizeof(T), (size_t) n,
                                hipMemcpyDeviceToHost));
   }
-  DLAF_HIP_CHECK(hipFree(dd));
-  DLAF_HIP_CHECK(hipFree(de));
-  DLAF_HIP_CHECK(hipFree(dv));
+  DLAF_HIP_CHECK(pool_free(dd));
+  DLAF_HIP_CHECK(pool_free(de));
+  DLAF_HIP_CHECK(pool_free(dv));
   return r;
 }
 
@@ -347,9 +347,9 @@ int bt_band_to_tridiag_device(long n, int band, const T* v, long ldv, T* e, long
   DLAF_HIP_CHECK(hipStreamSynchronize(s));
   phase("transposition back");
   for (T* q : {vx, wx, sm, tm, taus, w2})
-    DLAF_HIP_CHECK(hipFree(q));
+    DLAF_HIP_CHECK(pool_free(q));
   if (et)
-    DLAF_HIP_CHECK(hipFree(et));
+    DLAF_HIP_CHECK(pool_free(et));
   phase("frees");
   return 0;
 }
@@ -376,8 +376,8 @@ int bt_band_to_tridiag_host(long n, int band, const T* v, long ldv, T* e, long l
   DLAF_HIP_CHECK(hipMemcpy2DAsync(e, (size_t) lde * sizeof(T), de, (size_t) ldd * sizeof(T), (size_t) n * sizeof(T),
                                   (size_t) ncols, hipMemcpyDeviceToHost, s));
   DLAF_HIP_CHECK(hipStreamSynchronize(s));
-  DLAF_HIP_CHECK(hipFree(dv));
-  DLAF_HIP_CHECK(hipFree(de_alloc));
+  DLAF_HIP_CHECK(pool_free(dv));
+  DLAF_HIP_CHECK(pool_free(de_alloc));
   DLAF_HIP_CHECK(hipStreamDestroy(s));
   return r;
 }
@@ -433,8 +433,8 @@ int hermitian_eigensolver_device(DeviceMatrix<T>& A, real_t<T>* w_host, GeneralM
   info = agreed(band_to_tridiag_device(A, band, d, e, v, n));
   if (info != 0) {
     for (R* q : {d, e})
-      DLAF_HIP_CHECK(hipFree(q));
-    DLAF_HIP_CHECK(hipFree(v));
+      DLAF_HIP_CHECK(pool_free(q));
+    DLAF_HIP_CHECK(pool_free(v));
     return info;
   }
   R* wd = ealloc<R>((size_t) n);
@@ -459,9 +459,9 @@ int hermitian_eigensolver_device(DeviceMatrix<T>& A, real_t<T>* w_host, GeneralM
   launch_rows_to_tiles(el, lde, n, ncl, nb, C.rows.P, C.rows.shift(), C.ltr, C.ltc, C.tiles, s);
   DLAF_HIP_CHECK(hipStreamSynchronize(s));
   for (R* q : {d, e, wd, zr})
-    DLAF_HIP_CHECK(hipFree(q));
-  DLAF_HIP_CHECK(hipFree(v));
-  DLAF_HIP_CHECK(hipFree(el_alloc));
+    DLAF_HIP_CHECK(pool_free(q));
+  DLAF_HIP_CHECK(pool_free(v));
+  DLAF_HIP_CHECK(pool_free(el_alloc));
   info = agreed(bt_reduction_to_band_device(band, C, A, taus.data()));
   {
     double ms = 0, fl = 0;

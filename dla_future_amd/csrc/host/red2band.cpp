@@ -41,7 +41,7 @@ namespace {
 template <class T>
 T* dalloc(size_t elems) {
   T* p = nullptr;
-  DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(elems, 1) * sizeof(T)));
+  DLAF_HIP_CHECK(pool_malloc(reinterpret_cast<void**>(&p), std::max<size_t>(elems, 1) * sizeof(T)));
   return p;
 }
 template <class T>
@@ -536,13 +536,13 @@ int reduction_to_band_device(DeviceMatrix<T>& A, int band, T* taus_host) {
     DLAF_HIP_CHECK(hipEventDestroy(ev_rest[q]));
   }
   for (T* q : {qt, Vb[0], Vb[1], W, Xb[0], Xb[1], S, Tm, W2, taus, gpart, part_s, part_t})
-    DLAF_HIP_CHECK(hipFree(q));
-  DLAF_HIP_CHECK(hipFree(qr_scratch));
+    DLAF_HIP_CHECK(pool_free(q));
+  DLAF_HIP_CHECK(pool_free(qr_scratch));
   if (blocked_any) {
     for (T* q : {Pcm, hr_g, hr_l2, hr_r, hr_lu, hr_y1, hr_winv})
-      DLAF_HIP_CHECK(hipFree(q));
-    DLAF_HIP_CHECK(hipFree(hr_flag));
-    DLAF_HIP_CHECK(hipFree(hr_sync));
+      DLAF_HIP_CHECK(pool_free(q));
+    DLAF_HIP_CHECK(pool_free(hr_flag));
+    DLAF_HIP_CHECK(pool_free(hr_sync));
   }
   DLAF_HIP_CHECK(hipHostFree(hr_flag_host));
   g_last_panels[0] = panels_blocked;
@@ -772,7 +772,7 @@ int bt_reduction_to_band_device(int band, TileMatrix<T>& C, DeviceMatrix<T>& A, 
   DLAF_HIP_CHECK(hipEventDestroy(ev0));
   DLAF_HIP_CHECK(hipEventDestroy(ev1));
   for (T* q : {qt, V, W, S, Tm, W2H, taus, gpart, part_t})
-    DLAF_HIP_CHECK(hipFree(q));
+    DLAF_HIP_CHECK(pool_free(q));
   return 0;
 }
 

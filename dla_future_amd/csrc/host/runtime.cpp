@@ -7,6 +7,8 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <exception>
 #include <thread>
 
@@ -45,7 +47,106 @@ void runtime_finalize() {
   if (!g_initialized)
     return;
   (void) hipDeviceSynchronize();
+  pool_release();
   g_initialized = false;
+}
+
+// =============================================================================== workspace pool
+namespace {
+struct Pool {
+  std::mutex mu;
+  std::map<void*, size_t> live;            // handed out: pointer -> capacity
+  std::multimap<size_t, void*> idle;       // kept: capacity -> pointer
+  size_t idle_bytes = 0;
+};
+Pool& pool() {
+  static Pool p;
+  return p;
+}
+constexpr size_t kPoolMinBytes = (size_t) 4 << 20;
+size_t pool_cap_bytes() {
+  static const size_t cap = [] {
+    const char* e = std::getenv("DLAF_MI355X_POOL_GB");
+    return (size_t) (e ? std::max(0.0, std::atof(e)) : 64.0) << 30;
+  }();
+  return cap;
+}
+}  // namespace
+
+hipError_t pool_malloc(void** p, size_t bytes) {
+  if (bytes < kPoolMinBytes || pool_cap_bytes() == 0)
+    return hipMalloc(p, bytes);
+  Pool& pl = pool();
+  {
+    std::lock_guard<std::mutex> lk(pl.mu);
+    auto it = pl.idle.lower_bound(bytes);
+    if (it != pl.idle.end() && it->first <= bytes + bytes / 4 + ((size_t) 64 << 20)) {
+      *p = it->second;
+      pl.live[*p] = it->first;
+      pl.idle_bytes -= it->first;
+      pl.idle.erase(it);
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) {
+    // out of memory with blocks kept: give them back and try once more
+    (void) hipGetLastError();
+    pool_release();
+    e = hipMalloc(p, bytes);
+  }
+  if (e == hipSuccess) {
+    std::lock_guard<std::mutex> lk(pl.mu);
+    pl.live[*p] = bytes;
+  }
+  return e;
+}
+
+hipError_t pool_free(void* p) {
+  if (p == nullptr)
+    return hipSuccess;
+  Pool& pl = pool();
+  size_t cap = 0;
+  {
+    std::lock_guard<std::mutex> lk(pl.mu);
+    auto it = pl.live.find(p);
+    if (it != pl.live.end()) {
+      cap = it->second;
+      pl.live.erase(it);
+    }
+  }
+  if (cap == 0)
+    return hipFree(p);
+  (void) hipDeviceSynchronize();  // (hipFree's implicit synchronisation: nothing enqueued may still use the block)
+  std::vector<void*> drop;
+  {
+    std::lock_guard<std::mutex> lk(pl.mu);
+    pl.idle.emplace(cap, p);
+    pl.idle_bytes += cap;
+    while (pl.idle_bytes > pool_cap_bytes() && !pl.idle.empty()) {
+      auto big = std::prev(pl.idle.end());
+      drop.push_back(big->second);
+      pl.idle_bytes -= big->first;
+      pl.idle.erase(big);
+    }
+  }
+  for (void* q : drop)
+    (void) hipFree(q);
+  return hipSuccess;
+}
+
+void pool_release() {
+  Pool& pl = pool();
+  std::vector<void*> drop;
+  {
+    std::lock_guard<std::mutex> lk(pl.mu);
+    for (auto& kv : pl.idle)
+      drop.push_back(kv.second);
+    pl.idle.clear();
+    pl.idle_bytes = 0;
+  }
+  for (void* q : drop)
+    (void) hipFree(q);
 }
 
 bool runtime_initialized() {

@@ -29,6 +29,17 @@ namespace dlaf_mi355x {
   } while (0)
 
 // ------------------------------------------------------------------------------------------------
+// Workspace pool of the widenings (eigensolver stages): the reference takes its device temporaries from Umpire pools
+// (src/memory/memory_chunk.cpp, init.cpp:100-140); here hipMalloc / hipFree of the multi-gigabyte temporaries of
+// bt_band_to_tridiagonal and the divide & conquer solver cost 0.25-0.5 s per solve on some boxes (measured:
+// profiles/r04_eigensolver_alloc_phases.txt), so blocks of 4 MiB and more are kept for the next call instead of going
+// back to the driver.  pool_free waits for the device first (what hipFree does implicitly).  DLAF_MI355X_POOL_GB caps
+// what is kept (default 64, 0 = no pool); pool_release() gives everything back (dlaf_finalize).
+hipError_t pool_malloc(void** p, size_t bytes);
+hipError_t pool_free(void* p);
+void pool_release();
+
+// ------------------------------------------------------------------------------------------------
 // Transport: the broadcast primitive along a process row / column (communication/kernels/
 // internal/broadcast.h:36-119 in the reference: MPI_Ibcast).  Two implementations:
 //   * RCCL over xGMI: ncclBroadcast on device buffers, stream-ordered (the production path);

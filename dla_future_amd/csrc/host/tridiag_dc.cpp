@@ -19,7 +19,7 @@ namespace {
 template <class T>
 T* dcalloc(size_t elems) {
   T* p = nullptr;
-  DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(elems, 1) * sizeof(T)));
+  DLAF_HIP_CHECK(pool_malloc(reinterpret_cast<void**>(&p), std::max<size_t>(elems, 1) * sizeof(T)));
   return p;
 }
 struct Node {
@@ -230,15 +230,15 @@ int tridiag_solver_device(long n, int /*nb*/, R* d, R* e, R* w, R* z, long ldz, 
   DLAF_HIP_CHECK(hipMemcpyAsync(&h_info, info, sizeof(int), hipMemcpyDeviceToHost, s));
   DLAF_HIP_CHECK(hipStreamSynchronize(s));
   for (R* p : {q, qt, dlt, u, rv, d_rho})
-    DLAF_HIP_CHECK(hipFree(p));
-  DLAF_HIP_CHECK(hipFree(iv));
-  DLAF_HIP_CHECK(hipFree(rots));
-  DLAF_HIP_CHECK(hipFree(d_leaf_off));
-  DLAF_HIP_CHECK(hipFree(d_leaf_n));
-  DLAF_HIP_CHECK(hipFree(d_bounds));
-  DLAF_HIP_CHECK(hipFree(d_merges));
-  DLAF_HIP_CHECK(hipFree(d_headers));
-  DLAF_HIP_CHECK(hipFree(info));
+    DLAF_HIP_CHECK(pool_free(p));
+  DLAF_HIP_CHECK(pool_free(iv));
+  DLAF_HIP_CHECK(pool_free(rots));
+  DLAF_HIP_CHECK(pool_free(d_leaf_off));
+  DLAF_HIP_CHECK(pool_free(d_leaf_n));
+  DLAF_HIP_CHECK(pool_free(d_bounds));
+  DLAF_HIP_CHECK(pool_free(d_merges));
+  DLAF_HIP_CHECK(pool_free(d_headers));
+  DLAF_HIP_CHECK(pool_free(info));
   if (h_info != 0)
     fatal("[dlaf_mi355x] tridiagonal_eigensolver: the QL iteration of the leaf at row %d did not converge\n", h_info - 1);
   return 0;
@@ -264,7 +264,7 @@ int tridiag_solver_host(long n, int nb, const R* d, const R* e, R* w, R* z, long
                                   hipMemcpyDeviceToHost, s));
   DLAF_HIP_CHECK(hipStreamSynchronize(s));
   for (R* p : {dd, de, dw, dz})
-    DLAF_HIP_CHECK(hipFree(p));
+    DLAF_HIP_CHECK(pool_free(p));
   DLAF_HIP_CHECK(hipStreamDestroy(s));
   return r;
 }
