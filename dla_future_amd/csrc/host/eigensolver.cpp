@@ -180,9 +180,8 @@ int bt_band_to_tridiag_device(long n, int band, const T* v, long ldv, T* e, long
   T* sm = ealloc<T>(nb2 * (size_t) b * b);
   T* tm = ealloc<T>(nb2 * (size_t) b * b);
   T* taus = ealloc<T>(nb2 * (size_t) b);
-  DLAF_HIP_CHECK(hipMemsetAsync(vx, 0, nb2 * vblk * sizeof(T), s));
-  DLAF_HIP_CHECK(hipMemsetAsync(taus, 0, nb2 * (size_t) b * sizeof(T), s));
-  phase("allocations + memsets");
+  // (no memsets: the expansion writes every block (jb <= ib) in full, zeros included, and nothing reads the others)
+  phase("allocations");
   // fp64, band 128: the fused kernel (kernels_bt.hip) applies a block to a column strip in one go, on E transposed, and
   // streams V^T: the expansion writes that image directly (S = V^H V and W = V T take it as their operand);
   // DLAF_MI355X_BT_FUSED=0: the two strided-batch products per wavefront (every type, every band)
@@ -193,48 +192,57 @@ int bt_band_to_tridiag_device(long n, int band, const T* v, long ldv, T* e, long
   const bool fused = fused_on && bt_fused_supported(b, sizeof(T), TypeInfo<T>::is_complex);
   launch_b2t_expand(v, ldv, n, b, vx, taus, s, fused);
   const T one = make_host_el<T>(1.0), zero = make_host_el<T>(0.0), mone = make_host_el<T>(-1.0);
-  {
-    GemmArgs<T> g;  // S = V^H V  (fused: vx holds V^T, S = V^T (V^T)^H for the real types of that path)
-    g.M = b;
-    g.N = b;
-    g.K = 2 * b;
-    g.a = vx;
-    g.lda = fused ? b : 2 * b;
-    g.opa = fused ? 'N' : 'C';
-    g.b = vx;
-    g.ldb = fused ? b : 2 * b;
-    g.opb = fused ? 'C' : 'N';
-    g.c = sm;
-    g.ldc = b;
-    g.alpha = one;
-    g.beta = zero;
-    g.batch = (int) nb2;
-    g.sa = (long) vblk;
-    g.sb = (long) vblk;
-    g.sc = (long) b * b;
-    launch_gemm(g, s);
-  }
-  launch_tfactor(sm, (long) b, taus, b, tm, (long) b, s, (int) nb2, (long) b * b, (long) b, (long) b * b);
-  {
-    GemmArgs<T> g;  // W = V T
-    g.M = 2 * b;
-    g.N = b;
-    g.K = b;
-    g.a = vx;
-    g.lda = fused ? b : 2 * b;
-    g.opa = fused ? 'C' : 'N';
-    g.b = tm;
-    g.ldb = b;
-    g.opb = 'N';
-    g.c = wx;
-    g.ldc = 2 * b;
-    g.alpha = one;
-    g.beta = zero;
-    g.batch = (int) nb2;
-    g.sa = (long) vblk;
-    g.sb = (long) b * b;
-    g.sc = (long) vblk;
-    launch_gemm(g, s);
+  // Block (jb, ib) -- sweep group jb, rows 1 + ib b -- exists for jb <= ib only (ib = jb + step): the strided-batch
+  // launches below take one row of the block grid at a time, the blocks ib = jb .. nblk - 1 of sweep group jb, instead
+  // of all nblk^2 slots (half of which hold zeros: 28 ms of T factors alone at n = 20480)
+  const long jb_end = std::min<long>(nblk, (nsweeps - 1) / b + 1);
+  for (long jb = 0; jb < jb_end; ++jb) {
+    const size_t q0 = (size_t) jb * nblk + (size_t) jb;
+    const int cnt = (int) (nblk - jb);
+    {
+      GemmArgs<T> g;  // S = V^H V  (fused: vx holds V^T, S = V^T (V^T)^H for the real types of that path)
+      g.M = b;
+      g.N = b;
+      g.K = 2 * b;
+      g.a = vx + q0 * vblk;
+      g.lda = fused ? b : 2 * b;
+      g.opa = fused ? 'N' : 'C';
+      g.b = vx + q0 * vblk;
+      g.ldb = fused ? b : 2 * b;
+      g.opb = fused ? 'C' : 'N';
+      g.c = sm + q0 * (size_t) b * b;
+      g.ldc = b;
+      g.alpha = one;
+      g.beta = zero;
+      g.batch = cnt;
+      g.sa = (long) vblk;
+      g.sb = (long) vblk;
+      g.sc = (long) b * b;
+      launch_gemm(g, s);
+    }
+    launch_tfactor(sm + q0 * (size_t) b * b, (long) b, taus + q0 * (size_t) b, b, tm + q0 * (size_t) b * b, (long) b, s, cnt,
+                   (long) b * b, (long) b, (long) b * b);
+    {
+      GemmArgs<T> g;  // W = V T
+      g.M = 2 * b;
+      g.N = b;
+      g.K = b;
+      g.a = vx + q0 * vblk;
+      g.lda = fused ? b : 2 * b;
+      g.opa = fused ? 'C' : 'N';
+      g.b = tm + q0 * (size_t) b * b;
+      g.ldb = b;
+      g.opb = 'N';
+      g.c = wx + q0 * vblk;
+      g.ldc = 2 * b;
+      g.alpha = one;
+      g.beta = zero;
+      g.batch = cnt;
+      g.sa = (long) vblk;
+      g.sb = (long) b * b;
+      g.sc = (long) vblk;
+      launch_gemm(g, s);
+    }
   }
   phase("expand, S, T factors, W");
   double* et = nullptr;
