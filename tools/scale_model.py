@@ -47,13 +47,22 @@ class Rates:
             # in situ: shared compute units with the neighbouring bulk workgroups sitting out 1.0 ms (2.15 ms with
             # raised wave priority alone; profiles/r03_potrf_yield_ab.txt); on exclusive compute units 0.87 ms
             # (profiles/r03_exclusive_cus_ab.txt) -- the grid order's reservation with a device-side transport
-            self.potrf_alone, self.potrf_insitu, self.potrf_excl = 0.92e-3, 1.0e-3, 0.87e-3
+            # round 4 (profiles/r04_chain_bench.txt): grid order, strips registered for the yield (on grids again since
+            # round 4): 0.62 ms in situ, 0.60 alone; a ONE-tile panel solve 0.34 ms (16 workgroups, MFMA-latency bound),
+            # the update of the next column alone 0.16 ms
+            self.potrf_alone, self.potrf_insitu, self.potrf_excl = 0.60e-3, 0.62e-3, 0.60e-3
+            self.potrf_pairs = 0.97e-3      # in situ under the one-process (pairs) order
+            self.trsm_one, self.upd_one = 0.34e-3, 0.16e-3
         else:
             self.r_bulk = (67.8e12 if cx else 62.0e12)   # z in situ 67.8 (4N^3/3 model); d nb=512 bulk 0.79 of peak
             self.r_eff = (65.1e12 if cx else 60.6e12)    # round 3: z N=32768 nb=512 65.1, C1 60.6
             self.r_trsm = (30.0e12 if cx else 45.0e12)
-            self.potrf_alone, self.potrf_insitu = ((0.95e-3, 0.94e-3) if cx else (0.375e-3, 0.37e-3))
-            self.potrf_excl = 0.85e-3 if cx else 0.32e-3
+            # round 4 (profiles/r04_chain_bench.txt, z nb = 512): 0.525 ms in situ under the grid order, 0.54 alone,
+            # one-tile solve 0.30 ms, next-column update 0.15-0.19 ms
+            self.potrf_alone, self.potrf_insitu = ((0.54e-3, 0.525e-3) if cx else (0.375e-3, 0.37e-3))
+            self.potrf_excl = 0.525e-3 if cx else 0.32e-3
+            self.potrf_pairs = 0.945e-3 if cx else 0.37e-3
+            self.trsm_one, self.upd_one = ((0.30e-3, 0.17e-3) if cx else (0.12e-3, 0.06e-3))
         self.fill = 60e-6                   # fill + drain of a bulk launch (70.7 vs 68.8 TFlop/s at 33 ms: ~0.9 ms / 15 waves)
         self.elem = 16 if cx else 8
 
@@ -63,7 +72,11 @@ class Rates:
         return tiles * self.flop_gemm_tile / self.r_bulk + self.fill
 
     def t_trsm(self, rows):
-        return rows * self.flop_trsm_tile / self.r_trsm + (20e-6 if rows > 0 else 0.0)
+        # a tile is 16 (nb = 1024) workgroups of the row-owner kernel: below a GPU-full of tiles the launch takes as long
+        # as ONE wave needs for its 16 rows (measured: trsm_one), not flops / rate
+        if rows <= 0:
+            return 0.0
+        return max(self.trsm_one, rows * self.flop_trsm_tile / self.r_trsm + 20e-6)
 
 
 class Fabric:
@@ -97,10 +110,10 @@ def model(n, nb, pr, pc, cx, schedule, fab, reserve=32.0 / 512.0):
         bc_panel_t = fab.bcast(cols * tile_bytes, pr)
         work = (tiles * rt.flop_gemm_tile + rows * rt.flop_trsm_tile) / rt.r_eff   # (launch overheads are in R_eff)
         if schedule in ("early", "early-x"):
-            chain = (rt.potrf_excl if schedule == "early-x" else rt.potrf_insitu) + bc_diag + rt.t_trsm(1) + fab.bcast(tile_bytes, pc) + rt.t_bulk(1)
+            chain = (rt.potrf_excl if schedule == "early-x" else rt.potrf_insitu) + bc_diag + rt.t_trsm(1) + fab.bcast(tile_bytes, pc) + rt.upd_one
             step = max(tiles * rt.flop_gemm_tile / rt.r_eff + t_trsm, chain, bc_panel + bc_panel_t)
         else:
-            chain = rt.potrf_alone + bc_diag + t_trsm + bc_panel + bc_panel_t + t_la
+            chain = rt.potrf_pairs + bc_diag + t_trsm + bc_panel + bc_panel_t + t_la
             step = max(work, chain)
         if step > work * 1.02 + 1e-9:
             chain_bound += 1
