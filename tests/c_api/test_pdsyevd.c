@@ -197,7 +197,9 @@ int main(int argc, char** argv) {
   const int sizes[][3] = {{0, 2, 100},  {5, 8, 100},  {34, 34, 100}, {4, 3, 100}, {16, 10, 100},
                           {34, 13, 100}, {32, 5, 100}, {34, 8, 3},    {32, 6, 3}};
   int bad = 0;
-  for (unsigned s = 0; s < sizeof(sizes) / sizeof(sizes[0]); ++s) {
+  /* a one-process grid runs the whole list, several ranks every second entry (the Python worker runs the list on
+   * the six-rank grids as well) */
+  for (unsigned s = 0; s < sizeof(sizes) / sizeof(sizes[0]); s += (size > 1 ? 2 : 1)) {
     dlaf_mi355x_set_eigensolver_min_band(sizes[s][2]);
     for (int cx = 0; cx < 2; ++cx)
       for (int kind = 0; kind < 3; ++kind) {

@@ -61,6 +61,16 @@ def main():
     rank = dist.get_rank()
     ok = True
 
+    import time as _time
+    _t_last = [_time.time()]
+
+    def lap(what):
+        """DIST_WORKER_TIMING=1: wall time of the worker's sections (rank 0)"""
+        if os.environ.get("DIST_WORKER_TIMING") == "1" and rank == 0:
+            now = _time.time()
+            print(f"[dist_worker] section {what}: {now - _t_last[0]:.1f} s", flush=True)
+            _t_last[0] = now
+
     def said(cond, what):
         """a check that would otherwise fail without a word: say which one (every rank, once)"""
         if not cond:
@@ -116,6 +126,7 @@ def main():
                     print(f"[dist_worker] FAILED case {t}{uplo} n={n} nb={nb} grid {nprow}x{npcol}: max diff {md}", flush=True)
                 ok &= good
             ok &= said(bool((store[rows:, :] == 7.5).all()), "bool((store[rows:, :] == 7.5).all()) (line 118)")
+        lap("cholesky cases")
         # Communication pattern (recording transport): every member of a row / column communicator logs the SAME
         # sequence of broadcasts for it -- the reference's communicator-pipeline property
         # (sender/transform_mpi.h:60-75) -- under both issue orders a grid can run, and the transposed panel
@@ -167,6 +178,7 @@ def main():
         os.environ.pop("DLAF_MI355X_SCHEDULE", None)
         if sched0 is not None:
             os.environ["DLAF_MI355X_SCHEDULE"] = sched0
+        lap("schedules + comm log")
         # The grid order with the reservation a DEVICE-SIDE transport makes (RCCL kernels beside the bulk update:
         # DLAF_MI355X_COMM_SLOTS) forced onto this host-side one -- the path the first real 2 x 4 RCCL run takes
         # (replaces cholesky/impl.h:223-304) -- at a size whose bulk launches have more work items than the GPU has
@@ -182,7 +194,8 @@ def main():
             rows, cols = grid.local_shape(n, nb, sr, sc)
             loc = np.zeros((max(1, rows), max(1, cols)), order="F")[:rows, :cols]
             dlaf.set_random_hermitian_positive_definite(grid, loc, n, nb, sr, sc)
-            for uplo, comm_slots, want_exclusive in (("L", "60", True), ("U", "28", False)):
+            # (2 x 3: the exclusive-compute-unit run only; 2 x 2 both)
+            for uplo, comm_slots, want_exclusive in (("L", "60", True), ("U", "28", False))[:2 if (nprow, npcol) == (2, 2) else 1]:
                 os.environ["DLAF_MI355X_COMM_SLOTS"] = comm_slots
                 orig = dlaf.DeviceMatrix(grid, np.float64, uplo, n, nb, sr, sc)
                 fact = dlaf.DeviceMatrix(grid, np.float64, uplo, n, nb, sr, sc)
@@ -216,6 +229,7 @@ def main():
                 orig.close()
                 fact.close()
             os.environ.pop("DLAF_MI355X_COMM_SLOTS", None)
+        lap("reserved slots")
         # not positive definite: every rank must report the SAME LAPACK info (the reference aborts every rank,
         # src/cusolver/assert_info.cu:35-45, lapack/tile.h:374-378); nobody hangs, nobody returns 0
         # DIST_WORKER_NONSPD_REPEAT: the cases are run that many times (diagnosis of an intermittent failure; default 1)
@@ -254,6 +268,7 @@ def main():
                            f"{bad + 1}; trace {[hex(w) for w in (dlaf.potrf_trace() or [])]}")
             ok &= said(r_info == bad + 1, f"resident non-SPD {t}{uplo} n={n} nb={nb}: factorize() returned {r_info}, expected {bad + 1}")
             m.close()
+        lap("non-SPD")
         # device-side residual checker with the MAX reduction over the grid (miniapp check_cholesky)
         for t, uplo, n, nb in [("d", "L", 200, 32), ("z", "U", 90, 16)]:
             dt = oracle.DTYPES[t]
@@ -279,6 +294,7 @@ def main():
             ok &= bool(good)
             orig.close()
             fact.close()
+        lap("residual checker")
         # the widenings (solver, gen_to_std, eigensolver stages): not repeated by the runs that only select another
         # issue order of the Cholesky factorization (DIST_WORKER_CHOLESKY_ONLY=1)
         # DIST_WORKER_SKIP: sections of the widenings a run leaves to the other grids (hegst, red2band, b2t, eig)
@@ -288,8 +304,14 @@ def main():
             # triangular solver: every side / uplo / op / diag on the reference's analytic systems
             # (test/unit/solver/test_triangular.cpp:105-141), non-zero source ranks, both communication shapes
             import itertools
-            for t, (m, n, nb) in [("d", (19, 25, 6)), ("z", (15, 7, 3)), ("d", (150, 70, 32)), ("s", (12, 13, 5)),
-                                  ("d", (130, 200, 64))]:
+            # (all five operand sets on the two-rank grids and on 3 x 2; 2 x 2 and 2 x 3, which carry the reserved-slots
+            # run and the eigensolvers, take three resp. two of them: 24 variants each, 47 s of a 6-rank worker)
+            solver_sets = [("d", (19, 25, 6)), ("z", (15, 7, 3)), ("d", (150, 70, 32)), ("s", (12, 13, 5)), ("d", (130, 200, 64))]
+            if (nprow, npcol) == (2, 3):
+                solver_sets = [solver_sets[1], solver_sets[4]]
+            elif (nprow, npcol) == (2, 2):
+                solver_sets = [solver_sets[0], solver_sets[1], solver_sets[4]]
+            for t, (m, n, nb) in solver_sets:
                 dt = oracle.DTYPES[t]
                 alpha = dt(complex(-1.2, .7)) if t in "cz" else dt(-1.2)
                 for side, uplo, op, diag in itertools.product("LR", "LU", "NTC", "NU"):
@@ -307,8 +329,12 @@ def main():
                             print(f"[dist_worker] solver FAILED {t} {side}{uplo}{op}{diag} {m}x{n} nb={nb} "
                                   f"grid {nprow}x{npcol}: max diff {md} tol {tol}", flush=True)
                         ok &= bool(good)
+            lap("solver variants")
             # B with MB x NB blocks (MB != NB) and a source process of its own along the free dimension
-            for t, (m, n, mb, nb) in [("d", (19, 25, 6, 5)), ("z", (15, 7, 3, 5)), ("d", (150, 70, 32, 48)), ("s", (7, 8, 2, 9))]:
+            rect_sets = [("d", (19, 25, 6, 5)), ("z", (15, 7, 3, 5)), ("d", (150, 70, 32, 48)), ("s", (7, 8, 2, 9))]
+            if (nprow, npcol) in ((2, 3), (2, 2)):
+                rect_sets = [rect_sets[1], rect_sets[2]]
+            for t, (m, n, mb, nb) in rect_sets:
                 dt = oracle.DTYPES[t]
                 alpha = dt(complex(-1.2, .7)) if t in "cz" else dt(-1.2)
                 for side, uplo, op, diag in itertools.product("LR", "LU", "NTC", "NU"):
@@ -332,6 +358,7 @@ def main():
                             print(f"[dist_worker] solver (rectangular blocks) FAILED {t} {side}{uplo}{op}{diag} {m}x{n} "
                                   f"blocks {mb}x{nb} grid {nprow}x{npcol}: max diff {md} tol {tol}", flush=True)
                         ok &= bool(good)
+            lap("solver MB x NB")
             # generalized_to_standard on the grid: the reference's distributed test (test_gen_to_std.cpp:85-113) --
             # analytic operands, non-zero source rank, abs tolerance 10 (m+1) error, the factor untouched -- plus
             # random operands against the oracle's restatement of GenToStd::call_L
@@ -374,6 +401,7 @@ def main():
                     if not good:
                         print(f"[dist_worker] gen_to_std random FAILED {t}{uplo} n={n} nb={nb}: max diff {md} tol {tol}", flush=True)
                     ok &= bool(good)
+            lap("gen_to_std")
             # reduction_to_band + bt_reduction_to_band on the grid: the reference's distributed test
             # (test_reduction_to_band.cpp:405-489 -- its size lists on the 6-rank grids, checkResult: Q B Q^H == A within
             # n^2 * error, the upper triangle untouched) plus fast-path sizes, a non-zero source rank, elementwise against
@@ -422,6 +450,7 @@ def main():
                         print(f"[dist_worker] bt_reduction_to_band FAILED {t} n={n} nb={nb} band={band} k={k} grid {nprow}x{npcol}: "
                               f"max diff {np.abs(gotc - refc).max()} tol {tolc}", flush=True)
                     ok &= goodc
+            lap("red2band")
             # band_to_tridiagonal on the grid (test_band_to_tridiag.cpp:151-183: the reference's reconstruction check, a
             # non-zero source rank): every rank ends up with the whole tridiagonal matrix and reflectors, bit-identical
             from oracle import tridiag as td
@@ -443,6 +472,7 @@ def main():
                         print(f"[dist_worker] band_to_tridiagonal FAILED {t} n={n} nb={nb} band={band} grid {nprow}x{npcol}: {diff} {bar}",
                               flush=True)
                 ok &= bool(good)
+            lap("band_to_tridiag")
             # hermitian_eigensolver / hermitian_generalized_eigensolver on the grid through the reference's C entries
             # (test_eigensolver.cpp, test_gen_eigensolver.cpp: testEigensolverCorrectness on the gathered results; A and the
             # eigenvector matrix with different source columns)
@@ -474,6 +504,7 @@ def main():
                     if not good:
                         print(f"[dist_worker] hermitian_eigensolver FAILED {t} n={n} nb={nb} b_min={b_min} {kind} grid {nprow}x{npcol}: {res}", flush=True)
                 ok &= bool(good)
+            lap("eigensolver")
             # test_gen_eigensolver.cpp:66-72 (the same `sizes`), then two larger ones
             gen_cases = [("dzsc"[i % 4], n, nb, b_min) for i, (n, nb, b_min) in enumerate(ref_sizes) if n > 0]
             for t, n, nb, b_min in keep("eig", gen_cases + [("z", 130, 32, 100)]):
@@ -498,6 +529,7 @@ def main():
                         print(f"[dist_worker] generalized eigensolver FAILED {t} n={n} nb={nb} grid {nprow}x{npcol}: "
                               f"{np.abs(g_ - np.eye(n)).max()} {np.abs(r_).max()}", flush=True)
                     ok &= bool(good)
+            lap("gen eigensolver")
             # p?potrf -> p?potrs on resident matrices over the grid (no host staging between the factorization and the
             # two solves), and one resident solve per side against the oracle
             for t, uplo, n, nrhs, nb in [("d", "L", 300, 90, 32), ("z", "U", 200, 70, 32)]:
@@ -525,6 +557,7 @@ def main():
                     ok &= good
                 am.close()
                 bm.close()
+        lap("potrs")
         # analytic known-answer matrix through the ScaLAPACK-style entry (test_cholesky_c_api.cpp:108-155)
         n, nb = 34, 13
         a, l = oracle.cholesky_setters("L", n, np.float64)

@@ -49,6 +49,10 @@ def launch(mode, nprow, npcol, order, timeout, extra_env=None):
             if p.poll() is None:
                 p.kill()  # exact PIDs we started
     rc = [p.returncode for p in procs]
+    if os.environ.get("DIST_WORKER_TIMING") == "1":   # (diagnosis: where a worker spends its time)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", f"dist_timing_{mode}_{nprow}x{npcol}.log"), "w") as fh:
+            fh.write("".join(ln + "\n" for ln in outs[0][0].splitlines() if "section" in ln))
     if not (all(r == 0 for r in rc) and "DIST_WORKER_RESULT OK" in outs[0][0]):
         # the whole story of a failing run goes to a file (pytest truncates long assertion messages)
         try:
