@@ -449,7 +449,7 @@ int hermitian_eigensolver_device(DeviceMatrix<T>& A, real_t<T>* w_host, GeneralM
   R* zr = ealloc<R>((size_t) n * n);
   {
     StageTimer t(s);
-    tridiag_solver_device<R>(n, nb, d, e, wd, zr, n, s);
+    tridiag_solver_device<R>(n, nb, d, e, wd, zr, n, s, g->nranks > 1 ? grid_transport(*g) : nullptr);
     g_stage_ms[2] = t.stop();
   }
   DLAF_HIP_CHECK(hipMemcpyAsync(w_host, wd, (size_t) n * sizeof(R), hipMemcpyDeviceToHost, s));

@@ -29,7 +29,7 @@ int bt_band_to_tridiag_host(long n, int band, const T* v, long ldv, T* e, long l
 // eigenvalues w (device, n, ascending) and eigenvectors z (device, column-major n x n, ldz).  nb = the leaf size of the
 // divide & conquer tree (the block size of the reference's distribution, tridiag_solver/impl.h:198-262).
 template <class R>
-int tridiag_solver_device(long n, int nb, R* d, R* e, R* w, R* z, long ldz, hipStream_t s);
+int tridiag_solver_device(long n, int nb, R* d, R* e, R* w, R* z, long ldz, hipStream_t s, Transport* tr = nullptr);
 template <class R>
 int tridiag_solver_host(long n, int nb, const R* d, const R* e, R* w, R* z, long ldz);
 

@@ -73,10 +73,21 @@ int dc_leaf_size() {
 }
 }  // namespace
 
+// tr != null (a process grid): the solver still runs replicated -- leaves, deflation, secular equation, every rank
+// the same -- but the n^3 part, Q_new = Q_gathered U of the LARGE merges (the top levels of the tree: at least
+// DLAF_MI355X_DC_DIST_MIN rows, default 4096), is cut into one column slice per rank and the slices are exchanged with
+// one grouped broadcast round along the process rows and one along the process columns (an all-gather).  The reference
+// distributes the whole solver (tridiag_solver/impl.h:362-476, multiplyEigenvectors merge.h:1694-1790); here the
+// deflation and the secular equation are a few per cent of the stage and stay replicated.
 template <class R>
-int tridiag_solver_device(long n, int /*nb*/, R* d, R* e, R* w, R* z, long ldz, hipStream_t s) {
+int tridiag_solver_device(long n, int /*nb*/, R* d, R* e, R* w, R* z, long ldz, hipStream_t s, Transport* tr) {
   if (n <= 0)
     return 0;
+  const int P = tr ? tr->nprow * tr->npcol : 1;
+  static const long dist_min = [] {
+    const char* e_ = std::getenv("DLAF_MI355X_DC_DIST_MIN");
+    return e_ ? std::max(32L, std::atol(e_)) : 4096L;
+  }();
   const int leaf = dc_leaf_size();
   const long nleaves = (n + leaf - 1) / leaf;
   std::vector<long> leaf_off(nleaves + 1);
@@ -188,34 +199,62 @@ int tridiag_solver_device(long n, int /*nb*/, R* d, R* e, R* w, R* z, long ldz, 
       const R* qtb = qt + nd.off + nd.off * ldq;
       const R* ub = u + nd.off + nd.off * ldq;
       if (hd.k > 0) {
-        GemmArgs<R> g;
-        g.M = nd.n1;
-        g.N = hd.k;
-        g.K = hd.ku + hd.kd;
-        g.a = qtb;
-        g.lda = ldq;
-        g.opa = 'N';
-        g.b = ub;  // U^T: k x (classes), used transposed
-        g.ldb = ldq;
-        g.opb = 'C';
-        g.c = qb;
-        g.ldc = ldq;
-        g.alpha = one;
-        g.beta = zero;
-        if (g.K > 0)
-          gemm_main_tail(g, s);
-        else
-          DLAF_HIP_CHECK(hipMemset2DAsync(qb, (size_t) ldq * sizeof(R), 0, (size_t) nd.n1 * sizeof(R), (size_t) hd.k, s));
-        GemmArgs<R> g2 = g;
-        g2.M = nd.n2;
-        g2.K = hd.kd + hd.kl;
-        g2.a = qtb + nd.n1 + (long) hd.ku * ldq;
-        g2.b = ub + (long) hd.ku * ldq;
-        g2.c = qb + nd.n1;
-        if (g2.K > 0)
-          gemm_main_tail(g2, s);
-        else
-          DLAF_HIP_CHECK(hipMemset2DAsync(qb + nd.n1, (size_t) ldq * sizeof(R), 0, (size_t) nd.n2 * sizeof(R), (size_t) hd.k, s));
+        // the columns [c0, c1) of the non-deflated block this rank computes: all of them, or its slice
+        const bool split = P > 1 && nn >= dist_min && hd.k >= 16 * P;
+        auto cut = [&](int sidx) -> int { return sidx >= P ? hd.k : (int) (((long) hd.k * sidx / P) / 16 * 16); };
+        const int me = split ? tr->myrow * tr->npcol + tr->mycol : 0;
+        const int c0 = split ? cut(me) : 0, c1 = split ? cut(me + 1) : hd.k;
+        if (c1 > c0) {
+          GemmArgs<R> g;
+          g.M = nd.n1;
+          g.N = c1 - c0;
+          g.K = hd.ku + hd.kd;
+          g.a = qtb;
+          g.lda = ldq;
+          g.opa = 'N';
+          g.b = ub + c0;  // U^T: k x (classes), used transposed
+          g.ldb = ldq;
+          g.opb = 'C';
+          g.c = qb + (long) c0 * ldq;
+          g.ldc = ldq;
+          g.alpha = one;
+          g.beta = zero;
+          if (g.K > 0)
+            gemm_main_tail(g, s);
+          else
+            DLAF_HIP_CHECK(hipMemset2DAsync(g.c, (size_t) ldq * sizeof(R), 0, (size_t) nd.n1 * sizeof(R), (size_t) (c1 - c0), s));
+          GemmArgs<R> g2 = g;
+          g2.M = nd.n2;
+          g2.K = hd.kd + hd.kl;
+          g2.a = qtb + nd.n1 + (long) hd.ku * ldq;
+          g2.b = ub + (long) hd.ku * ldq + c0;
+          g2.c = qb + nd.n1 + (long) c0 * ldq;
+          if (g2.K > 0)
+            gemm_main_tail(g2, s);
+          else
+            DLAF_HIP_CHECK(hipMemset2DAsync(g2.c, (size_t) ldq * sizeof(R), 0, (size_t) nd.n2 * sizeof(R), (size_t) (c1 - c0), s));
+        }
+        if (split) {
+          // all-gather of the slices as whole columns of q (outside the merge's diagonal block they are zero on every
+          // rank): slice r npcol + c belongs to rank (r, c), so a process row ends up with a contiguous run of columns
+          R* colbase = q + nd.off * ldq;
+          tr->group_begin();
+          for (int c = 0; c < tr->npcol; ++c) {
+            const int a0 = cut(tr->myrow * tr->npcol + c), a1 = cut(tr->myrow * tr->npcol + c + 1);
+            if (a1 > a0 && tr->npcol > 1)
+              tr->bcast(CommAxis::Row, c, tr->mycol, colbase + (long) a0 * ldq, colbase + (long) a0 * ldq,
+                        (size_t) ldq * (size_t) (a1 - a0) * sizeof(R), s);
+          }
+          tr->group_end();
+          tr->group_begin();
+          for (int r = 0; r < tr->nprow; ++r) {
+            const int a0 = cut(r * tr->npcol), a1 = cut((r + 1) * tr->npcol);
+            if (a1 > a0 && tr->nprow > 1)
+              tr->bcast(CommAxis::Col, r, tr->myrow, colbase + (long) a0 * ldq, colbase + (long) a0 * ldq,
+                        (size_t) ldq * (size_t) (a1 - a0) * sizeof(R), s);
+          }
+          tr->group_end();
+        }
       }
       if (hd.k < nn)
         DLAF_HIP_CHECK(hipMemcpy2DAsync(qb + (long) hd.k * ldq, (size_t) ldq * sizeof(R), qtb + (long) hd.k * ldq,
@@ -258,7 +297,7 @@ int tridiag_solver_host(long n, int nb, const R* d, const R* e, R* w, R* z, long
   DLAF_HIP_CHECK(hipMemcpyAsync(dd, d, (size_t) n * sizeof(R), hipMemcpyHostToDevice, s));
   if (n > 1)
     DLAF_HIP_CHECK(hipMemcpyAsync(de, e, (size_t) (n - 1) * sizeof(R), hipMemcpyHostToDevice, s));
-  const int r = tridiag_solver_device(n, nb, dd, de, dw, dz, n, s);
+  const int r = tridiag_solver_device<R>(n, nb, dd, de, dw, dz, n, s, nullptr);
   DLAF_HIP_CHECK(hipMemcpyAsync(w, dw, (size_t) n * sizeof(R), hipMemcpyDeviceToHost, s));
   DLAF_HIP_CHECK(hipMemcpy2DAsync(z, (size_t) ldz * sizeof(R), dz, (size_t) n * sizeof(R), (size_t) n * sizeof(R), (size_t) n,
                                   hipMemcpyDeviceToHost, s));
@@ -269,8 +308,8 @@ int tridiag_solver_host(long n, int nb, const R* d, const R* e, R* w, R* z, long
   return r;
 }
 
-template int tridiag_solver_device<float>(long, int, float*, float*, float*, float*, long, hipStream_t);
-template int tridiag_solver_device<double>(long, int, double*, double*, double*, double*, long, hipStream_t);
+template int tridiag_solver_device<float>(long, int, float*, float*, float*, float*, long, hipStream_t, Transport*);
+template int tridiag_solver_device<double>(long, int, double*, double*, double*, double*, long, hipStream_t, Transport*);
 template int tridiag_solver_host<float>(long, int, const float*, const float*, float*, float*, long);
 template int tridiag_solver_host<double>(long, int, const double*, const double*, double*, double*, long);
 

@@ -97,6 +97,8 @@ def main():
             ok &= said(bool(np.array_equal(full, oracle.set_random_hpd(n, nb, np.float64))), "bool(np.array_equal(full, oracle.set_random_hpd(n, nb, np.float64))) (line 87)")
         grid.barrier()
     else:
+        if nprow * npcol == 6:
+            os.environ.setdefault("DLAF_MI355X_DC_DIST_MIN", "64")   # (read once by the library: see the eigensolver cases)
         dlaf.initialize()
         ok &= said(grid.selftest(3 << 14) == 0, "grid.selftest(3 << 14) == 0 (line 91)")  # row / column communicator wiring through the Transport interface
         cases = [("d", "L", 150, 32), ("d", "U", 150, 32), ("z", "L", 100, 16), ("z", "U", 70, 16),
@@ -304,11 +306,13 @@ def main():
             # triangular solver: every side / uplo / op / diag on the reference's analytic systems
             # (test/unit/solver/test_triangular.cpp:105-141), non-zero source ranks, both communication shapes
             import itertools
-            # (all five operand sets on the two-rank grids and on 3 x 2; 2 x 2 and 2 x 3, which carry the reserved-slots
-            # run and the eigensolvers, take three resp. two of them: 24 variants each, 47 s of a 6-rank worker)
+            # (all five operand sets on the two-rank grids; the grids with four and six ranks share them out -- 24 variants
+            # each, 47 s of a 6-rank worker for all five -- so that every set runs on a six-rank grid)
             solver_sets = [("d", (19, 25, 6)), ("z", (15, 7, 3)), ("d", (150, 70, 32)), ("s", (12, 13, 5)), ("d", (130, 200, 64))]
             if (nprow, npcol) == (2, 3):
                 solver_sets = [solver_sets[1], solver_sets[4]]
+            elif (nprow, npcol) == (3, 2):
+                solver_sets = [solver_sets[0], solver_sets[2], solver_sets[3]]
             elif (nprow, npcol) == (2, 2):
                 solver_sets = [solver_sets[0], solver_sets[1], solver_sets[4]]
             for t, (m, n, nb) in solver_sets:
@@ -334,6 +338,8 @@ def main():
             rect_sets = [("d", (19, 25, 6, 5)), ("z", (15, 7, 3, 5)), ("d", (150, 70, 32, 48)), ("s", (7, 8, 2, 9))]
             if (nprow, npcol) in ((2, 3), (2, 2)):
                 rect_sets = [rect_sets[1], rect_sets[2]]
+            elif (nprow, npcol) == (3, 2):
+                rect_sets = [rect_sets[0], rect_sets[3]]
             for t, (m, n, mb, nb) in rect_sets:
                 dt = oracle.DTYPES[t]
                 alpha = dt(complex(-1.2, .7)) if t in "cz" else dt(-1.2)
@@ -484,6 +490,15 @@ def main():
             eig_cases = [("sdcz"[i % 4], n, nb, i % 2, b_min, "random") for i, (n, nb, b_min) in enumerate(ref_sizes)]
             eig_cases += [("d", 8, 4, 1, 4, "identity"), ("z", 34, 8, 1, 4, "identity")]
             eig_cases += [("d", 300, 32, 1, 100, "random"), ("z", 260, 64, 0, 100, "random"), ("d", 1100, 256, 1, 100, "random")]
+            # The 2 x 2 grid (which leaves the lists above to 2 x 3) runs ONE larger solve: at N = 4096 the top merge of the
+            # divide & conquer tree reaches the default size from which Q_new = Q U is cut into one column slice per rank
+            # and all-gathered (tridiag_dc.cpp; the 2 x 3 run lowers that size so that its small cases take the path too)
+            if "eig" in skip and (nprow, npcol) == (2, 2):
+                skip = skip - {"eig"}
+                eig_cases = [("d", 4096, 256, 1, 100, "random")]
+                gen_only_big = True
+            else:
+                gen_only_big = False
             for t, n, nb, src, b_min, kind in keep("eig", eig_cases):
                 dt = oracle.DTYPES[t]
                 sr, sc = (max(0, nprow - 1), min(1, npcol - 1)) if src else (0, 0)
@@ -507,7 +522,7 @@ def main():
             lap("eigensolver")
             # test_gen_eigensolver.cpp:66-72 (the same `sizes`), then two larger ones
             gen_cases = [("dzsc"[i % 4], n, nb, b_min) for i, (n, nb, b_min) in enumerate(ref_sizes) if n > 0]
-            for t, n, nb, b_min in keep("eig", gen_cases + [("z", 130, 32, 100)]):
+            for t, n, nb, b_min in keep("eig", [] if gen_only_big else gen_cases + [("z", 130, 32, 100)]):
                 dt = oracle.DTYPES[t]
                 sr, sc = max(0, nprow - 1), min(1, npcol - 1)
                 dlaf.eigensolver_min_band(b_min)
