@@ -185,11 +185,24 @@ int reduction_to_band_device(DeviceMatrix<T>& A, int band, T* taus_host) {
   // holds panel p + 1 on the panel stream, everything else on a second stream -- so that the latency-bound panel
   // kernel of p + 1 runs beside the bulk of the update of p; X = A W of p + 1 waits for both.
   // DLAF_MI355X_R2B_LOOKAHEAD=1 turns it on (off by default, see below).
-  static const bool want_lookahead = [] {
+  // DLAF_MI355X_R2B_LOOKAHEAD=0/1 forces it; default: on where the panel is factored blocked (a chain of small kernels
+  // that finds room beside the update: 27.9 -> 30.0 TFlop/s at N = 20480, nb = 512, profiles/r04_red2band_lookahead_ab.txt),
+  // off with the reflector-by-reflector kernel (measured in round 3: no gain, its 1024-thread workgroups need whole CUs)
+  static const int want_lookahead = [] {
     const char* e = std::getenv("DLAF_MI355X_R2B_LOOKAHEAD");
-    return e ? std::atoi(e) != 0 : false;  // measured: no gain (the panel kernel's 1024-thread workgroups need whole CUs)
+    return e ? (std::atoi(e) != 0 ? 1 : 0) : -1;
   }();
-  const bool lookahead = want_lookahead && !dist && A.s_low != A.s_high;
+  const bool blocked_panels = panel_qr_blocked_supported(b, std::max<long>(n - b, 0), b, sizeof(T), TypeInfo<T>::is_complex);
+  const bool lookahead = (want_lookahead < 0 ? blocked_panels : want_lookahead != 0) && !dist && A.s_low != A.s_high;
+  // workgroup slots the bulk of the trailing update leaves to the panel chain beside it (DLAF_MI355X_R2B_SLOTS; a plain
+  // launch's queued workgroups are not overtaken by the side stream's kernels)
+  static const long la_slots = [] {
+    const char* e = std::getenv("DLAF_MI355X_R2B_SLOTS");
+    return e ? std::max(0L, std::atol(e)) : 0L;  // measured: 0 (plain launch) 30.0, 64 28.5, 96 28.7, 160 29.7, 256 29.6 TFlop/s
+  }();
+  unsigned* la_counters = nullptr;
+  if (lookahead && la_slots > 0)
+    DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&la_counters), 32 * sizeof(unsigned)));
   hipStream_t s2 = lookahead ? A.s_low : s;
   hipEvent_t ev_x[2], ev_rest[2];
   for (int q = 0; q < 2; ++q) {
@@ -467,7 +480,8 @@ int reduction_to_band_device(DeviceMatrix<T>& A, int band, T* taus_host) {
       launch_gemm(g, s);
     }
     // ---- 6. A_t -= X V^H + V X^H on the lower tiles (tile::her2k / 2 x tile::gemm, impl.h:545-585) ----------------
-    auto her2k = [&](long ja, long jb, hipStream_t st) {
+    // reserve > 0: persistent form that leaves that many workgroup slots to the panel chain running beside it
+    auto her2k = [&](long ja, long jb, hipStream_t st, long reserve = 0) {
       if (il0 >= ltr || ja >= jb)
         return;
       UpdateArgs<T> ua;
@@ -498,7 +512,12 @@ int reduction_to_band_device(DeviceMatrix<T>& A, int band, T* taus_host) {
       ua.nt = (int) nt;
       ua.last_rows = rows.last_extent();
       ua.info = info;
-      launch_update(ua, st, 3);
+      if (reserve > 0 && la_counters != nullptr) {
+        unsigned* cnt = la_counters + 16 * (size_t) (p & 1);
+        launch_update(ua, st, 3, std::max<long>(64, A.bulk_slots - reserve), cnt, false);
+      }
+      else
+        launch_update(ua, st, 3);
     };
     if (lookahead) {
       // the tile column of the next panel first, on the panel stream; the rest beside the next panel chain
@@ -506,7 +525,7 @@ int reduction_to_band_device(DeviceMatrix<T>& A, int band, T* taus_host) {
       DLAF_HIP_CHECK(hipEventRecord(ev_x[p & 1], s));
       her2k(jl0, jsplit, s);
       DLAF_HIP_CHECK(hipStreamWaitEvent(s2, ev_x[p & 1], 0));
-      her2k(jsplit, ltc, s2);
+      her2k(jsplit, ltc, s2, la_slots);
       DLAF_HIP_CHECK(hipEventRecord(ev_rest[p & 1], s2));
     }
     else
@@ -545,6 +564,8 @@ int reduction_to_band_device(DeviceMatrix<T>& A, int band, T* taus_host) {
     DLAF_HIP_CHECK(pool_free(hr_sync));
   }
   DLAF_HIP_CHECK(hipHostFree(hr_flag_host));
+  if (la_counters)
+    DLAF_HIP_CHECK(hipFree(la_counters));
   g_last_panels[0] = panels_blocked;
   g_last_panels[1] = panels_fallback;
   if (h_info == kInfoSchedulingFailure)
