@@ -120,6 +120,10 @@ void launch_hr_transpose(T* qt, int b, long m, T* cm, long ld, bool to_cm, const
 // not finite; zeroes the strict upper triangle of l
 template <class T>
 void launch_hr_gate(T* l, int ld, int b, double limit, int* flag, hipStream_t stream);
+// g2 = Q1^T Q1 after the first pass: within `tol` of the identity -> g2 := I, *skip = 1 (the second pass returns at
+// once: it takes `skip` as its status word); farther than 0.1 -> *flag
+template <class T>
+void launch_hr_orth(T* g2, int ld, int b, double tol, int* skip, int* flag, hipStream_t stream);
 // Householder reconstruction of the top b x b block from it and R = L2^T L1^T (see kernels_hr.hip: hr_lu_kernel)
 template <class T>
 void launch_hr_lu(T* q, long ldq, int b, const T* rmat, T* lu, T* y1, T* tb, T* taus, const int* flag, hipStream_t stream);

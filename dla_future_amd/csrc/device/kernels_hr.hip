@@ -107,6 +107,51 @@ __global__ __launch_bounds__(256) void hr_gate_kernel(T* l, int ld, int b, T lim
     atomicCAS(flag, 0, 1);
 }
 
+// After the first CholeskyQR pass: g2 = Q1^T Q1 (b x b, ld).  When it equals the identity to `tol` (max norm) the
+// second pass would change nothing above rounding -- the panels of a random matrix have condition numbers close to 1
+// and come out of ONE pass orthonormal to a few 1e-15 -- so g2 is replaced by the identity (its "Cholesky factor":
+// R = L2^T L1^T = L1^T) and *skip is raised: the second factorization and solve, which take `skip` as their status
+// word, return at once.  A g2 that is far from the identity (> 0.1) means the first pass failed outright: *flag.
+template <class T>
+__global__ __launch_bounds__(256) void hr_orth_kernel(T* g2, int ld, int b, T tol, int* skip, int* flag) {
+  __shared__ T red[256];
+  if (*flag != 0)
+    return;
+  T mx = 0;
+  for (int idx = threadIdx.x; idx < b * b; idx += 256) {
+    const int r = idx % b, c = idx / b;
+    if (r >= c) {
+      T v = g2[r + (long) c * ld] - (r == c ? T(1) : T(0));
+      v = v < 0 ? -v : v;
+      mx = (v > mx || !(v == v)) ? v : mx;  // (a NaN wins)
+    }
+  }
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int) threadIdx.x < off) {
+      const T o = red[threadIdx.x + off];
+      if (o > red[threadIdx.x] || !(o == o))
+        red[threadIdx.x] = o;
+    }
+    __syncthreads();
+  }
+  const T m = red[0];
+  if (!(m <= T(0.1))) {
+    if (threadIdx.x == 0)
+      atomicCAS(flag, 0, 2);
+    return;
+  }
+  if (m <= tol) {
+    for (int idx = threadIdx.x; idx < b * b; idx += 256) {
+      const int r = idx % b, c = idx / b;
+      g2[r + (long) c * ld] = (r == c) ? T(1) : T(0);
+    }
+    if (threadIdx.x == 0)
+      *skip = 1;
+  }
+}
+
 // One workgroup of NT threads.  In: the top b x b block of Q (column-major, ldq), R = L2^T L1^T (b x b, ld b, upper).
 // Out:
 //   top block of Q  <-  xGEQR2's output: S R on and above the diagonal, V1 strictly below it
@@ -236,6 +281,11 @@ void launch_hr_gate(T* l, int ld, int b, double limit, int* flag, hipStream_t st
 }
 
 template <class T>
+void launch_hr_orth(T* g2, int ld, int b, double tol, int* skip, int* flag, hipStream_t stream) {
+  hipLaunchKernelGGL((hr_orth_kernel<T>), dim3(1), dim3(256), 0, stream, g2, ld, b, (T) tol, skip, flag);
+}
+
+template <class T>
 void launch_hr_lu(T* q, long ldq, int b, const T* rmat, T* lu, T* y1, T* tb, T* taus, const int* flag, hipStream_t stream) {
   constexpr int NT = 1024;
   if (b == 128)
@@ -253,6 +303,7 @@ void hr_kernels_init() {}
 #define INST(T)                                                                                            \
   template void launch_hr_transpose<T>(T*, int, long, T*, long, bool, const int*, hipStream_t);            \
   template void launch_hr_gate<T>(T*, int, int, double, int*, hipStream_t);                                \
+  template void launch_hr_orth<T>(T*, int, int, double, int*, int*, hipStream_t);                          \
   template void launch_hr_lu<T>(T*, long, int, const T*, T*, T*, T*, T*, const int*, hipStream_t);
 INST(float)
 INST(double)

@@ -34,7 +34,7 @@ line = [l for l in open(out + "/bench_under_pmc_FETCH_SIZE.log") if l.startswith
 wl = json.loads(line[-1])["config"] if line else {}
 rec = {"workload": wl.get("workload"), "grid": wl.get("grid"), "kernel": "update_kernel<double,true,0>",
        "launches_per_factorization": n, "fetch_size_GB_corrected": fetch, "write_size_GB": write,
-       "bytes_per_launch": (fetch + write) * 1e9 / max(n, 1), "source": "profiles/r03_pmc_hbm_traffic_N65536_nb1024.txt",
+       "bytes_per_launch": (fetch + write) * 1e9 / max(n, 1), "source": "profiles/r04_pmc_hbm_traffic_N65536_nb1024.txt",
        "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes with --kernel-trace over one factorization "
                  "(bench.py --steps 1 --warmup 0); FETCH_SIZE x2 (gfx950); includes Infinity-Cache hits"}
 json.dump(rec, open(out + "/pmc_traffic.json", "w"), indent=1)

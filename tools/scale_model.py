@@ -124,6 +124,32 @@ def model(n, nb, pr, pc, cx, schedule, fab, reserve=32.0 / 512.0):
     return total, tf, tf * 1e12 / (pr * pc * PEAK), chain_bound, nt
 
 
+def model_c5(pr, pc, fab):
+    """BASELINE configs[4]: the Hermitian eigensolver at N = 20480, nb = 512 (band 128), fp64, on a pr x pc grid.  Stage
+    times of one MI355X measured in round 4 (profiles/r04_eigensolver_N20480_nb512_bench.txt), split into the part every
+    rank repeats (replicated) and the part the grid shares; communication from the guide's xGMI figures.  What is
+    replicated today: the panel factorization of reduction_to_band inside the owning process column (and the T / W / W2
+    products every rank recomputes), band_to_tridiagonal (one persistent bulge-chasing launch per rank),
+    the deflation / secular part of the divide & conquer solver; bt_band_to_tridiagonal is shared over process COLUMNS
+    only (each rank applies it to all rows of its columns)."""
+    n, b = 20480, 128
+    P = pr * pc
+    npanels = (n - b - 1 + b - 1) // b
+    # stage 1: panel chain (blocked: 0.65 ms per panel) + T / W / W2 (0.10 ms) replicated; hemm + her2k shared
+    t1_rep, t1_sh = npanels * 0.75e-3, 0.255
+    # per panel: the factored panel along the process row, the all-reduce of X over the grid (m x b doubles each, m ~ n / 2)
+    msg = (n / 2) * b * 8
+    t1_comm = npanels * (fab.bcast(msg, pc) + (2 * fab.bcast(msg, P) if P > 1 else 0.0))
+    t2 = 0.548 + (2 * fab.bcast(2 * b * n * 8, P) if P > 1 else 0.0)
+    # stage 3: Q U of the large merges shared (0.17 s of GEMMs), the rest replicated; all-gather of n x n doubles at the top
+    # level, half of that at each level below (seven links per GPU)
+    t3 = 0.12 + 0.17 / P + ((2.0 * n * n * 8 * (P - 1) / P) / (7 * fab.bw) + 4 * fab.lat if P > 1 else 0.0)
+    t4 = 0.473 / pc
+    t5 = 0.313 / P + (npanels / 4) * fab.bcast((n / 2) * 512 * 8, pc) * (1 if P > 1 else 0)
+    t1 = t1_rep + t1_sh / P + t1_comm
+    return t1, t2, t3, t4, t5
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--bw", type=float, default=64e9)
@@ -139,6 +165,16 @@ def main():
                 t, tf, frac, cb, nt = model(n, nb, pr, pc, cx, sched, fab)
                 print(f"| {pr}x{pc} | {sched} | {t * 1e3:.0f} | {tf:.1f} | {frac:.3f} | {cb} / {nt} |")
         print()
+    print(f"## C5  d hermitian_eigensolver N=20480 nb=512 band=128   (xGMI {a.bw / 1e9:.0f} GB/s per peer, {a.lat * 1e6:.0f} us per collective)")
+    print("| grid | reduction_to_band | band_to_tridiagonal | tridiagonal_eigensolver | bt_band_to_tridiagonal | bt_reduction_to_band | total [s] | speed-up |")
+    print("|---|---|---|---|---|---|---|---|")
+    base = None
+    for pr, pc in ((1, 1), (1, 2), (2, 2), (2, 4)):
+        st = model_c5(pr, pc, fab)
+        tot = sum(st)
+        base = base or tot
+        print(f"| {pr}x{pc} | " + " | ".join(f"{x:.3f}" for x in st) + f" | {tot:.2f} | {base / tot:.2f} |")
+    print()
 
 
 if __name__ == "__main__":
