@@ -90,6 +90,36 @@ def compute_panel_reflectors(p: np.ndarray, nrefls: int) -> np.ndarray:
     return taus
 
 
+def panel_reflectors_blocked(p: np.ndarray):
+    """The BLOCKED panel factorization of the MI355X build (csrc/device/kernels_hr.hip, red2band.cpp), restated in numpy
+    so that it can be pinned on the CPU against compute_panel_reflectors / LAPACK ?geqrf: CholeskyQR2, then the
+    Householder representation of Q reconstructed by an LU factorization without pivoting of Q - [S; 0] with
+    S = diag(-sign(Re q_jj)) chosen during the elimination (Ballard et al., "Reconstructing Householder vectors from
+    TSQR", IPDPS 2014).  p: m x b, m >= b, full column rank.  Returns (out, taus, t): `out` in xGEQR2's layout (S R on and
+    above the diagonal of the top block, the reflectors below), taus = -u_jj s_j, t = -U S V1^-H (the T factor)."""
+    m, b = p.shape
+    g = p.conj().T @ p
+    l1 = np.linalg.cholesky(g)
+    q = np.linalg.solve(l1, p.conj().T).conj().T          # P L1^-H
+    l2 = np.linalg.cholesky(q.conj().T @ q)
+    q = np.linalg.solve(l2, q.conj().T).conj().T
+    r = l2.conj().T @ l1.conj().T
+    w = q[:b, :].copy()
+    sgn = np.zeros(b)
+    for j in range(b):
+        sgn[j] = -1.0 if w[j, j].real >= 0 else 1.0
+        w[j, j] -= sgn[j]
+        w[j + 1:, j] /= w[j, j]
+        w[j + 1:, j + 1:] -= np.outer(w[j + 1:, j], w[j, j + 1:])
+    y1 = np.tril(w, -1) + np.eye(b, dtype=p.dtype)
+    u = np.triu(w)
+    y2 = np.linalg.solve(u.T, q[b:, :].T).T               # Q2 U^-1
+    taus = (-np.diag(u) * sgn).astype(p.dtype)
+    t = np.linalg.solve(y1.conj(), (-u * sgn[None, :]).T).T   # (-U S) V1^-H
+    out = np.vstack([np.tril(y1, -1) + np.triu(sgn[:, None] * r), y2]).astype(p.dtype)
+    return out, taus, t.astype(p.dtype)
+
+
 def well_formed_v(p: np.ndarray, nrefls: int) -> np.ndarray:
     """setupReflectorPanelV (:364-422): the first nrefls columns as a unit lower trapezoidal matrix."""
     v = np.tril(p[:, :nrefls], -1).copy()

@@ -90,3 +90,26 @@ def test_back_transformation_is_q_times_c(dt):
 
 def test_band_size_rule():
     assert [rb.get_band_size(nb) for nb in (512, 1024, 256, 64, 100, 200, 300, 99)] == [128, 128, 128, 64, 100, 100, 100, 99]
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.complex128])
+def test_blocked_panel_factorization_reproduces_geqr2(dt):
+    """CholeskyQR2 + Householder reconstruction (oracle.red2band.panel_reflectors_blocked: the numpy restatement of what
+    csrc/device/kernels_hr.hip does on the GPU) gives xGEQR2's reflectors, taus, R -- LAPACK's sign convention included --
+    and the T factor of xLARFT, element by element: against this oracle's reflector-by-reflector restatement
+    (impl.h:297-361) and against LAPACK ?geqrf itself."""
+    import scipy.linalg as sl
+    rng = np.random.default_rng(3)
+    for m, b in [(300, 16), (500, 128), (2000, 128), (260, 64), (130, 128)]:
+        p0 = rng.uniform(-1, 1, (m, b)).astype(dt)
+        if np.dtype(dt).kind == "c":
+            p0 = p0 + 1j * rng.uniform(-1, 1, (m, b))
+        out, taus, t = rb.panel_reflectors_blocked(p0.copy())
+        ref = np.asfortranarray(p0.copy())
+        rtaus = rb.compute_panel_reflectors(ref, b)
+        tol = 50 * m * rb.error_of(dt)
+        assert np.abs(out - ref).max() <= tol and np.abs(taus - rtaus).max() <= tol, (m, b, np.abs(out - ref).max())
+        qr, tl = (sl.lapack.zgeqrf if np.dtype(dt).kind == "c" else sl.lapack.dgeqrf)(p0)[:2]
+        assert np.abs(out - qr).max() <= tol and np.abs(taus - tl).max() <= tol
+        v = rb.well_formed_v(out, b)
+        assert np.abs(t - rb.compute_t_factor(v, taus)).max() <= tol
