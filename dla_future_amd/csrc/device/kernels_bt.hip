@@ -142,6 +142,14 @@ __global__ __launch_bounds__(256, 2) void bt_apply_kernel(const double* __restri
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // The slot re-staged below (chunk t + 3 -> slot (t - 1) % 4) was READ in the previous iteration: those ds_reads must
+    // have RETURNED -- not merely been issued -- before any wave passes this barrier and issues LDS-DMA into the slot
+    // (cdna_hip_programming.md, "restage a buffer >= 2 phases after its last ds_read, or 1 phase after when an lgkmcnt
+    // before the barrier retired those reads").  Without this wait the kernel gave wrong eigenvectors in a few per cent
+    // of runs as soon as four or more processes shared the GPU (LDS queues and the DMA path loaded differently: the
+    // DMA landed before a delayed read) and never alone -- found in round 4 at N = 4096 on a 2 x 2 grid
+    // (tools/diag_eig1.py; the round-3 grid cases were too small to hit it).
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (t + kBtStages - 1 < kChunks)
       issue(t + kBtStages - 1);

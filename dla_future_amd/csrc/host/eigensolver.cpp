@@ -175,6 +175,21 @@ int bt_band_to_tridiag_device(long n, int band, const T* v, long ldv, T* e, long
                  std::chrono::duration<double, std::milli>(now - t_last).count());
     t_last = now;
   };
+  static const bool dbg = [] {
+    const char* e_ = std::getenv("DLAF_MI355X_EIG_DEBUG");
+    return e_ && std::atoi(e_) != 0;
+  }();
+  auto checksum = [&](const char* what, const void* dev, size_t bytes) {
+    if (!dbg)
+      return;
+    DLAF_HIP_CHECK(hipStreamSynchronize(s));
+    std::vector<unsigned long long> h((bytes + 7) / 8, 0ull);
+    DLAF_HIP_CHECK(hipMemcpy(h.data(), dev, bytes, hipMemcpyDeviceToHost));
+    unsigned long long acc = 1469598103934665603ull;
+    for (unsigned long long x : h)
+      acc = (acc ^ x) * 1099511628211ull;
+    std::fprintf(stderr, "[dlaf_mi355x] bt debug %-22s %016llx\n", what, acc);
+  };
   T* vx = ealloc<T>(nb2 * vblk);
   T* wx = ealloc<T>(nb2 * vblk);
   T* sm = ealloc<T>(nb2 * (size_t) b * b);
@@ -244,6 +259,24 @@ int bt_band_to_tridiag_device(long n, int band, const T* v, long ldv, T* e, long
       launch_gemm(g, s);
     }
   }
+  if (dbg) {
+    // existing blocks only (the others are never written): block row jb, blocks jb .. nblk - 1
+    DLAF_HIP_CHECK(hipStreamSynchronize(s));
+    for (const char* nm : {"vx", "wx", "tm"}) {
+      unsigned long long acc = 1469598103934665603ull;
+      for (long jb = 0; jb < jb_end; ++jb) {
+        const size_t q0 = (size_t) jb * nblk + (size_t) jb, cnt = (size_t) (nblk - jb);
+        const bool is_t = nm[0] == 't';
+        const size_t per = is_t ? (size_t) b * b : vblk;
+        const T* base = (nm[0] == 'v' ? vx : (nm[0] == 'w' ? wx : tm)) + q0 * per;
+        std::vector<unsigned long long> h(cnt * per * sizeof(T) / 8);
+        DLAF_HIP_CHECK(hipMemcpy(h.data(), base, cnt * per * sizeof(T), hipMemcpyDeviceToHost));
+        for (unsigned long long x : h)
+          acc = (acc ^ x) * 1099511628211ull;
+      }
+      std::fprintf(stderr, "[dlaf_mi355x] bt debug %-22s %016llx\n", nm, acc);
+    }
+  }
   phase("expand, S, T factors, W");
   double* et = nullptr;
   const long ldet = (ncols + 63) / 64 * 64;
@@ -253,6 +286,8 @@ int bt_band_to_tridiag_device(long n, int band, const T* v, long ldv, T* e, long
       launch_bt_transpose(e, lde, n, ncols, et, ldet, s);
     }
   }
+  if (et)
+    checksum("et after transpose", et, (size_t) ldet * n * sizeof(double));
   phase("transposition");
   // steps of sweep group jb (its first sweep has the most)
   auto steps_of = [&](long jb) -> long {
@@ -347,6 +382,8 @@ int bt_band_to_tridiag_device(long n, int band, const T* v, long ldv, T* e, long
       run(q, 1, n - (1 + ib * b));
     }
   }
+  if (et)
+    checksum("et after wavefronts", et, (size_t) ldet * n * sizeof(double));
   phase("wavefronts");
   if constexpr (std::is_same_v<T, double>) {
     if (fused)
@@ -426,8 +463,25 @@ int hermitian_eigensolver_device(DeviceMatrix<T>& A, real_t<T>* w_host, GeneralM
       fatal("[dlaf_mi355x] eigensolver: n = %ld needs %.1f GiB per rank for the replicated stages (band_to_tridiagonal, "
             "tridiagonal_eigensolver), %.1f GiB are free\n", n, need / 1073741824.0, (double) free_b / 1073741824.0);
   }
+  // DLAF_MI355X_EIG_DEBUG=1: a checksum of every stage's output per rank (diagnosis: each stage is deterministic)
+  static const bool dbg = [] {
+    const char* e_ = std::getenv("DLAF_MI355X_EIG_DEBUG");
+    return e_ && std::atoi(e_) != 0;
+  }();
+  auto checksum = [&](const char* what, const void* dev, size_t bytes) {
+    if (!dbg)
+      return;
+    DLAF_HIP_CHECK(hipStreamSynchronize(s));
+    std::vector<unsigned long long> h((bytes + 7) / 8, 0ull);
+    DLAF_HIP_CHECK(hipMemcpy(h.data(), dev, bytes, hipMemcpyDeviceToHost));
+    unsigned long long acc = 1469598103934665603ull;
+    for (unsigned long long x : h)
+      acc = (acc ^ x) * 1099511628211ull;
+    std::fprintf(stderr, "[dlaf_mi355x] eig debug rank (%d,%d) %-24s %016llx\n", g->myrow, g->mycol, what, acc);
+  };
   std::vector<T> taus((size_t) std::max<long>(0, n - band - 1) + 1);
   int info = agreed(reduction_to_band_device(A, band, taus.data()));
+  checksum("A after red2band", A.tiles, (size_t) A.ltr * A.ltc * A.tile_elems * sizeof(T));
   {
     double ms = 0, fl = 0;
     red2band_last_profile(&ms, &fl);
@@ -445,6 +499,9 @@ int hermitian_eigensolver_device(DeviceMatrix<T>& A, real_t<T>* w_host, GeneralM
     DLAF_HIP_CHECK(pool_free(v));
     return info;
   }
+  checksum("d", d, (size_t) n * sizeof(R));
+  checksum("e", e, (size_t) (n - 1) * sizeof(R));
+  checksum("v", v, (size_t) n * n * sizeof(T));
   R* wd = ealloc<R>((size_t) n);
   R* zr = ealloc<R>((size_t) n * n);
   {
@@ -452,6 +509,8 @@ int hermitian_eigensolver_device(DeviceMatrix<T>& A, real_t<T>* w_host, GeneralM
     tridiag_solver_device<R>(n, nb, d, e, wd, zr, n, s, g->nranks > 1 ? grid_transport(*g) : nullptr);
     g_stage_ms[2] = t.stop();
   }
+  checksum("w", wd, (size_t) n * sizeof(R));
+  checksum("z (tridiagonal)", zr, (size_t) n * n * sizeof(R));
   DLAF_HIP_CHECK(hipMemcpyAsync(w_host, wd, (size_t) n * sizeof(R), hipMemcpyDeviceToHost, s));
   // the columns of this process column, all rows (the back-transformation mixes rows, never columns)
   const long ncl = C.cols.local_size();
@@ -464,13 +523,16 @@ int hermitian_eigensolver_device(DeviceMatrix<T>& A, real_t<T>* w_host, GeneralM
     bt_band_to_tridiag_device(n, band, v, n, el, lde, ncl, s);
     g_stage_ms[3] = t.stop();
   }
+  checksum("E after bt_b2t", el, (size_t) lde * std::max<long>(ncl, 1) * sizeof(T));
   launch_rows_to_tiles(el, lde, n, ncl, nb, C.rows.P, C.rows.shift(), C.ltr, C.ltc, C.tiles, s);
   DLAF_HIP_CHECK(hipStreamSynchronize(s));
   for (R* q : {d, e, wd, zr})
     DLAF_HIP_CHECK(pool_free(q));
   DLAF_HIP_CHECK(pool_free(v));
   DLAF_HIP_CHECK(pool_free(el_alloc));
+  checksum("C before bt_red2band", C.tiles, (size_t) C.ltr * C.ltc * C.tile_elems * sizeof(T));
   info = agreed(bt_reduction_to_band_device(band, C, A, taus.data()));
+  checksum("C after bt_red2band", C.tiles, (size_t) C.ltr * C.ltc * C.tile_elems * sizeof(T));
   {
     double ms = 0, fl = 0;
     red2band_last_profile(&ms, &fl);

@@ -168,9 +168,9 @@ public:
     if (bytes == 0)
       return;
     reserve(bytes);
-    DLAF_HIP_CHECK(hipStreamSynchronize(stream));
     if (my_index == root)
-      DLAF_HIP_CHECK(hipMemcpy(pinned_, send, bytes, hipMemcpyDeviceToHost));
+      DLAF_HIP_CHECK(hipMemcpyAsync(pinned_, send, bytes, hipMemcpyDeviceToHost, stream));
+    DLAF_HIP_CHECK(hipStreamSynchronize(stream));
     if (bcast_(user_, (int) axis, root, pinned_, bytes) != 0)
       fatal("[dlaf_mi355x] host broadcast callback failed\n");
     DLAF_HIP_CHECK(hipMemcpyAsync(recv, pinned_, bytes, hipMemcpyHostToDevice, stream));
@@ -207,8 +207,10 @@ public:
     const size_t nreal = count * ((type == 'c' || type == 'z') ? 2 : 1);
     const size_t bytes = nreal * (dbl ? sizeof(double) : sizeof(float));
     reserve(2 * bytes);
+    // (copies on the caller's stream + its synchronisation: the null stream the blocking hipMemcpy would use is not
+    //  ordered with the non-blocking stream the consumers of `dev` run on)
+    DLAF_HIP_CHECK(hipMemcpyAsync(pinned_, dev, bytes, hipMemcpyDeviceToHost, stream));
     DLAF_HIP_CHECK(hipStreamSynchronize(stream));
-    DLAF_HIP_CHECK(hipMemcpy(pinned_, dev, bytes, hipMemcpyDeviceToHost));
     char* mine = static_cast<char*>(pinned_);
     char* tmp = mine + bytes;
     std::vector<char> acc(bytes);
@@ -241,7 +243,8 @@ public:
       }
       std::memcpy(mine, acc.data(), bytes);
     }
-    DLAF_HIP_CHECK(hipMemcpy(dev, mine, bytes, hipMemcpyHostToDevice));
+    DLAF_HIP_CHECK(hipMemcpyAsync(dev, mine, bytes, hipMemcpyHostToDevice, stream));
+    DLAF_HIP_CHECK(hipStreamSynchronize(stream));
   }
 
 private:

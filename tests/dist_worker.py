@@ -100,6 +100,42 @@ def main():
         if nprow * npcol == 6:
             os.environ.setdefault("DLAF_MI355X_DC_DIST_MIN", "64")   # (read once by the library: see the eigensolver cases)
         dlaf.initialize()
+        if os.environ.get("DIST_WORKER_ONLY") == "eigbig":
+            # diagnosis: only the large eigensolver case, several times (DIST_WORKER_REPEAT)
+            from oracle import red2band as rb
+            from oracle import tridiag as td
+            t, n, nb = "d", int(os.environ.get("DIST_WORKER_N", "4096")), 256
+            dt = oracle.DTYPES[t]
+            for it in range(int(os.environ.get("DIST_WORKER_REPEAT", "3"))):
+                sr, sc = max(0, nprow - 1), min(1, npcol - 1)
+                a0 = rb.random_hermitian(n, dt, seed=700 + n)
+                la = np.asfortranarray(oracle.scatter(a0, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
+                w, lz = dlaf.hermitian_eigensolver(grid, "L", la, nb, sr, sc, n=n, z_jsrc=sc, z_shape=grid.local_shape(n, nb, sr, sc))
+                z = gather_global(lz, grid, n, nb, sr, sc, oracle)
+                if rank == 0:
+                    res = td.check_eigensolver(a0, w, z)
+                    print(f"[dist_worker] eigbig iteration {it}: orth {res['orth']:.2e} residual {res['residual']:.2e} "
+                          f"panels {dlaf.red2band_panel_stats()}", flush=True)
+            # stage by stage: every stage is deterministic, so its output must repeat bit for bit from run to run
+            import hashlib
+            band = dlaf.get_band_size(nb)
+            sr, sc = max(0, nprow - 1), min(1, npcol - 1)
+            a0 = rb.random_hermitian(n, dt, seed=700 + n)
+            ab = rb.random_hermitian(n, dt, seed=701 + n, banded=band)
+            for it in range(int(os.environ.get("DIST_WORKER_REPEAT", "3"))):
+                la = np.asfortranarray(oracle.scatter(a0, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
+                taus = dlaf.reduction_to_band(grid, la, nb, band, sr, sc, n=n)
+                h1 = hashlib.md5(la.tobytes() + taus.tobytes()).hexdigest()[:8]
+                lb = np.asfortranarray(oracle.scatter(ab, nb, nprow, npcol, sr, sc)[(grid.myrow, grid.mycol)])
+                d_, e_, v_ = dlaf.band_to_tridiagonal(grid, lb, nb, band, sr, sc, n=n)
+                h2 = hashlib.md5(d_.tobytes() + e_.tobytes() + v_.tobytes()).hexdigest()[:8]
+                hs = [None] * dist.get_world_size()
+                dist.all_gather_object(hs, (h1, h2))
+                if rank == 0:
+                    print(f"[dist_worker] eigbig stage hashes {it}: red2band {[h[0] for h in hs]} b2t {[h[1] for h in hs]}", flush=True)
+            grid.barrier()
+            print("DIST_WORKER_RESULT OK", flush=True)
+            return
         ok &= said(grid.selftest(3 << 14) == 0, "grid.selftest(3 << 14) == 0 (line 91)")  # row / column communicator wiring through the Transport interface
         cases = [("d", "L", 150, 32), ("d", "U", 150, 32), ("z", "L", 100, 16), ("z", "U", 70, 16),
                  ("s", "L", 96, 32), ("c", "U", 64, 16), ("d", "L", 34, 13), ("d", "L", 5, 8), ("d", "U", 260, 64),
