@@ -25,6 +25,45 @@ namespace {
 
 constexpr int kHrTile = 32;
 
+// element arithmetic for real and complex T (cplx<R>: .re, .im)
+template <class T>
+__device__ __forceinline__ T h_mul(const T& a, const T& b) {
+  if constexpr (TypeInfo<T>::is_complex)
+    return T{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+  else
+    return a * b;
+}
+template <class T>
+__device__ __forceinline__ T h_sub(const T& a, const T& b) {
+  if constexpr (TypeInfo<T>::is_complex)
+    return T{a.re - b.re, a.im - b.im};
+  else
+    return a - b;
+}
+template <class T>
+__device__ __forceinline__ T h_div(const T& a, const T& b) {
+  if constexpr (TypeInfo<T>::is_complex) {
+    const real_t<T> den = b.re * b.re + b.im * b.im;
+    return T{(a.re * b.re + a.im * b.im) / den, (a.im * b.re - a.re * b.im) / den};
+  }
+  else
+    return a / b;
+}
+template <class T>
+__device__ __forceinline__ T h_conj(const T& a) {
+  if constexpr (TypeInfo<T>::is_complex)
+    return T{a.re, -a.im};
+  else
+    return a;
+}
+template <class T>
+__device__ __forceinline__ T h_scale(const T& a, real_t<T> f) {
+  if constexpr (TypeInfo<T>::is_complex)
+    return T{a.re * f, a.im * f};
+  else
+    return a * f;
+}
+
 // dst[r + c * ldd] = src[c + r * b]  (to_cm != 0: transposed panel -> column-major), or back.  `flag` (may be null):
 // nothing is written when *flag != 0.
 template <class T>
@@ -73,28 +112,29 @@ __global__ __launch_bounds__(256) void hr_transpose_kernel(T* qt, int b, long m,
 // finite, the flag is raised.  The strict upper triangle of l -- which the factorization leaves as it found it -- is
 // zeroed, so that R = L2^T L1^T can be formed by the general product.  One workgroup.
 template <class T>
-__global__ __launch_bounds__(256) void hr_gate_kernel(T* l, int ld, int b, T limit, int* flag) {
+__global__ __launch_bounds__(256) void hr_gate_kernel(T* l, int ld, int b, real_t<T> limit, int* flag) {
+  using R = real_t<T>;
   if (*flag != 0)
     return;
   for (int idx = threadIdx.x; idx < b * b; idx += 256) {
     const int r = idx % b, c = idx / b;
     if (r < c)
-      l[r + (long) c * ld] = T(0);
+      l[r + (long) c * ld] = zero_el<T>();
   }
   if (threadIdx.x >= 64)
     return;
-  T mx = 0, mn = 0;
+  R mx = 0, mn = 0;
   bool bad = false, first = true;
   for (int j = threadIdx.x; j < b; j += 64) {
-    const T d = l[j + (long) j * ld];
-    if (!(d > T(0)) || !(d < T(1e300)))
+    const R d = re_of(l[j + (long) j * ld]);
+    if (!(d > R(0)) || !(d < R(1e300)))
       bad = true;
     mx = first ? d : (d > mx ? d : mx);
     mn = first ? d : (d < mn ? d : mn);
     first = false;
   }
   for (int off = 32; off > 0; off >>= 1) {
-    const T omx = __shfl_xor(mx, off), omn = __shfl_xor(mn, off);
+    const R omx = __shfl_xor(mx, off), omn = __shfl_xor(mn, off);
     const int ofirst = __shfl_xor(first ? 1 : 0, off);
     if (!ofirst) {
       mx = first ? omx : (omx > mx ? omx : mx);
@@ -103,7 +143,7 @@ __global__ __launch_bounds__(256) void hr_gate_kernel(T* l, int ld, int b, T lim
     }
     bad = bad || (__shfl_xor(bad ? 1 : 0, off) != 0);
   }
-  if (threadIdx.x == 0 && (bad || (limit > T(0) && !(mx <= limit * mn))))
+  if (threadIdx.x == 0 && (bad || (limit > R(0) && !(mx <= limit * mn))))
     atomicCAS(flag, 0, 1);
 }
 
@@ -113,16 +153,21 @@ __global__ __launch_bounds__(256) void hr_gate_kernel(T* l, int ld, int b, T lim
 // R = L2^T L1^T = L1^T) and *skip is raised: the second factorization and solve, which take `skip` as their status
 // word, return at once.  A g2 that is far from the identity (> 0.1) means the first pass failed outright: *flag.
 template <class T>
-__global__ __launch_bounds__(256) void hr_orth_kernel(T* g2, int ld, int b, T tol, int* skip, int* flag) {
-  __shared__ T red[256];
+__global__ __launch_bounds__(256) void hr_orth_kernel(T* g2, int ld, int b, real_t<T> tol, int* skip, int* flag) {
+  using R = real_t<T>;
+  __shared__ R red[256];
   if (*flag != 0)
     return;
-  T mx = 0;
+  R mx = 0;
   for (int idx = threadIdx.x; idx < b * b; idx += 256) {
     const int r = idx % b, c = idx / b;
     if (r >= c) {
-      T v = g2[r + (long) c * ld] - (r == c ? T(1) : T(0));
+      const T e = g2[r + (long) c * ld];
+      R v = re_of(e) - (r == c ? R(1) : R(0));
       v = v < 0 ? -v : v;
+      R vi = im_of(e);
+      vi = vi < 0 ? -vi : vi;
+      v = (vi > v || !(vi == vi)) ? vi : v;
       mx = (v > mx || !(v == v)) ? v : mx;  // (a NaN wins)
     }
   }
@@ -130,14 +175,14 @@ __global__ __launch_bounds__(256) void hr_orth_kernel(T* g2, int ld, int b, T to
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
     if ((int) threadIdx.x < off) {
-      const T o = red[threadIdx.x + off];
+      const R o = red[threadIdx.x + off];
       if (o > red[threadIdx.x] || !(o == o))
         red[threadIdx.x] = o;
     }
     __syncthreads();
   }
-  const T m = red[0];
-  if (!(m <= T(0.1))) {
+  const R m = red[0];
+  if (!(m <= R(0.1))) {
     if (threadIdx.x == 0)
       atomicCAS(flag, 0, 2);
     return;
@@ -145,7 +190,7 @@ __global__ __launch_bounds__(256) void hr_orth_kernel(T* g2, int ld, int b, T to
   if (m <= tol) {
     for (int idx = threadIdx.x; idx < b * b; idx += 256) {
       const int r = idx % b, c = idx / b;
-      g2[r + (long) c * ld] = (r == c) ? T(1) : T(0);
+      g2[r + (long) c * ld] = make_el<T>((r == c) ? R(1) : R(0), R(0));
     }
     if (threadIdx.x == 0)
       *skip = 1;
@@ -168,9 +213,10 @@ __global__ __launch_bounds__(256) void hr_orth_kernel(T* g2, int ld, int b, T to
 template <class T, int NT, int RPT>
 __global__ __launch_bounds__(NT) void hr_lu_kernel(T* q, long ldq, int b, const T* rmat, T* lu, T* y1, T* tb, T* taus,
                                                    const int* flag) {
+  using R = real_t<T>;
   __shared__ T colbuf[2][128];
   __shared__ T rowbuf[2][128];
-  __shared__ T sg[128];
+  __shared__ R sg[128];
   __shared__ T pv[128];
   if (*flag != 0)
     return;
@@ -193,8 +239,9 @@ __global__ __launch_bounds__(NT) void hr_lu_kernel(T* q, long ldq, int b, const 
   for (int j = 0; j < b; ++j) {
     const int par = j & 1;
     const T wjj = rowbuf[par][j];
-    const T s = (wjj >= T(0)) ? T(-1) : T(1);
-    const T piv = wjj - s;
+    // (complex panels: the REAL sign -sign(Re w_jj) reproduces xLARFG's real beta, and |w_jj - s| >= 1 still holds)
+    const R s = (re_of(wjj) >= R(0)) ? R(-1) : R(1);
+    const T piv = make_el<T>(re_of(wjj) - s, im_of(wjj));
     if (t == 0) {
       sg[j] = s;
       pv[j] = piv;
@@ -203,17 +250,31 @@ __global__ __launch_bounds__(NT) void hr_lu_kernel(T* q, long ldq, int b, const 
     // share the row group, b >= 64, and a wave whose highest column is done has nothing to do at all), so they are
     // scalar branches around the reads and multiply-adds instead of per-lane selects on every element
     if (cmax > j) {
-      const T u = (c > j) ? rowbuf[par][c] / piv : T(0);  // u_jc / u_jj
-      const int k0 = (j >= gs) ? (j - gs) / G + 1 : 0;    // first row index of the thread that is still active
-      T l[RPT];
+      const T u = (c > j) ? h_div(rowbuf[par][c], piv) : zero_el<T>();  // u_jc / u_jj
+      const int k0 = (j >= gs) ? (j - gs) / G + 1 : 0;                  // first row index of the thread that is still active
+      // in chunks of up to 8 (complex: 4) rows: the chunk's multipliers are read together (one LDS latency per chunk), chunks whose
+      // rows are all done are skipped by a scalar branch, the chunk that straddles the boundary masks per element
+      constexpr int CHW = sizeof(T) == 16 ? 4 : 8;  // (16 complex rows are half the register file of a 1024-thread group)
+      constexpr int CH = RPT < CHW ? RPT : CHW;
 #pragma unroll
-      for (int k = 0; k < RPT; ++k)
-        if (k >= k0)
-          l[k] = colbuf[par][gs + G * k];
+      for (int kk = 0; kk < RPT; kk += CH) {
+        if (kk + CH > k0) {
+          T l[CH];
 #pragma unroll
-      for (int k = 0; k < RPT; ++k)
-        if (k >= k0)
-          w[k] = __builtin_fma(-l[k], u, w[k]);
+          for (int e = 0; e < CH; ++e)
+            l[e] = colbuf[par][gs + G * (kk + e)];
+#pragma unroll
+          for (int e = 0; e < CH; ++e) {
+            const bool on = kk + e >= k0;
+            const T lm = make_el<T>(on ? re_of(l[e]) : R(0), on ? im_of(l[e]) : R(0));
+            if constexpr (TypeInfo<T>::is_complex)
+              w[kk + e] = T{__builtin_fma(lm.im, u.im, __builtin_fma(-lm.re, u.re, w[kk + e].re)),
+                            __builtin_fma(-lm.im, u.re, __builtin_fma(-lm.re, u.im, w[kk + e].im))};
+            else
+              w[kk + e] = __builtin_fma(-lm, u, w[kk + e]);
+          }
+        }
+      }
     }
     // hand column j + 1 and row j + 1 to the next step
     const int jn = j + 1;
@@ -228,30 +289,31 @@ __global__ __launch_bounds__(NT) void hr_lu_kernel(T* q, long ldq, int b, const 
         T v = w[0];
 #pragma unroll
         for (int k = 1; k < RPT; ++k)
-          v = (k == kn) ? w[k] : v;
+          v = make_el<T>((k == kn) ? re_of(w[k]) : re_of(v), (k == kn) ? im_of(w[k]) : im_of(v));
         rowbuf[par ^ 1][c] = v;
       }
     }
     __syncthreads();
   }
   // ---- outputs ----------------------------------------------------------------------------------------------------------
-  const T pc = pv[c], sc = sg[c];
+  const T pc = pv[c];
+  const R sc = sg[c];
 #pragma unroll
   for (int k = 0; k < RPT; ++k) {
     const int r = g + G * k;
-    T yv = 0, uv = 0;
+    T yv = zero_el<T>(), uv = zero_el<T>();
     if (r > c)
-      yv = w[k] / pc;  // V1, strictly lower
+      yv = h_div(w[k], pc);  // V1, strictly lower
     else if (r == c)
       uv = pc;
     else
-      uv = w[k];       // U, strictly upper
-    y1[r + (long) c * b] = r > c ? yv : (r == c ? T(1) : T(0));
-    lu[c + (long) r * b] = r <= c ? uv : T(0);          // element (c, r) of U^T
-    tb[r + (long) c * b] = r <= c ? -uv * sc : T(0);    // -U S: column c scaled by s_c
-    q[r + (long) c * ldq] = r > c ? yv : sg[r] * rmat[r + (long) c * b];
+      uv = w[k];             // U, strictly upper
+    y1[r + (long) c * b] = r > c ? yv : make_el<T>(r == c ? R(1) : R(0), R(0));
+    lu[c + (long) r * b] = r <= c ? h_conj(uv) : zero_el<T>();           // element (c, r) of U^H
+    tb[r + (long) c * b] = r <= c ? h_scale(uv, -sc) : zero_el<T>();     // -U S: column c scaled by s_c
+    q[r + (long) c * ldq] = r > c ? yv : h_scale(rmat[r + (long) c * b], sg[r]);
     if (r == c)
-      taus[c] = -pc * sc;
+      taus[c] = h_scale(pc, -sc);
   }
 }
 
@@ -262,9 +324,9 @@ bool panel_qr_blocked_supported(int b, long m, int nr, size_t elem_size, bool is
     const char* e = std::getenv("DLAF_MI355X_QR_BLOCKED");
     return e ? std::atoi(e) != 0 : true;
   }();
-  // fp64 panels with whole 64-column blocks, a full set of reflectors and at least 2 b rows; everything else
-  // (complex and single precision, the last panels of a matrix, narrow bands) keeps the reflector-by-reflector kernel
-  return on && !is_complex && elem_size == 8 && (b == 64 || b == 128) && nr == b && m >= 2L * b;
+  // double-precision panels (real and complex) of band 64 / 128 with a full set of reflectors and at least 2 b rows;
+  // everything else (single precision, the last panels of a matrix, other bands) keeps the reflector-by-reflector kernel
+  return on && ((!is_complex && elem_size == 8) || (is_complex && elem_size == 16)) && (b == 64 || b == 128) && nr == b && m >= 2L * b;
 }
 
 template <class T>
@@ -277,19 +339,25 @@ void launch_hr_transpose(T* qt, int b, long m, T* cm, long ld, bool to_cm, const
 
 template <class T>
 void launch_hr_gate(T* l, int ld, int b, double limit, int* flag, hipStream_t stream) {
-  hipLaunchKernelGGL((hr_gate_kernel<T>), dim3(1), dim3(256), 0, stream, l, ld, b, (T) limit, flag);
+  hipLaunchKernelGGL((hr_gate_kernel<T>), dim3(1), dim3(256), 0, stream, l, ld, b, (real_t<T>) limit, flag);
 }
 
 template <class T>
 void launch_hr_orth(T* g2, int ld, int b, double tol, int* skip, int* flag, hipStream_t stream) {
-  hipLaunchKernelGGL((hr_orth_kernel<T>), dim3(1), dim3(256), 0, stream, g2, ld, b, (T) tol, skip, flag);
+  hipLaunchKernelGGL((hr_orth_kernel<T>), dim3(1), dim3(256), 0, stream, g2, ld, b, (real_t<T>) tol, skip, flag);
 }
 
 template <class T>
 void launch_hr_lu(T* q, long ldq, int b, const T* rmat, T* lu, T* y1, T* tb, T* taus, const int* flag, hipStream_t stream) {
   constexpr int NT = 1024;
-  if (b == 128)
-    hipLaunchKernelGGL((hr_lu_kernel<T, NT, 16>), dim3(1), dim3(NT), 0, stream, q, ldq, b, rmat, lu, y1, tb, taus, flag);
+  if (b == 128) {
+    // (complex double: 16 rows of a column are 64 registers, too many beside the multipliers in a 1024-thread group's
+    //  128-register budget; 512 threads with 32 rows each have 256)
+    if constexpr (sizeof(T) == 16)
+      hipLaunchKernelGGL((hr_lu_kernel<T, 512, 32>), dim3(1), dim3(512), 0, stream, q, ldq, b, rmat, lu, y1, tb, taus, flag);
+    else
+      hipLaunchKernelGGL((hr_lu_kernel<T, NT, 16>), dim3(1), dim3(NT), 0, stream, q, ldq, b, rmat, lu, y1, tb, taus, flag);
+  }
   else if (b == 64)
     hipLaunchKernelGGL((hr_lu_kernel<T, NT, 4>), dim3(1), dim3(NT), 0, stream, q, ldq, b, rmat, lu, y1, tb, taus, flag);
   else {
@@ -307,6 +375,7 @@ void hr_kernels_init() {}
   template void launch_hr_lu<T>(T*, long, int, const T*, T*, T*, T*, T*, const int*, hipStream_t);
 INST(float)
 INST(double)
+INST(cdouble)
 #undef INST
 
 }  // namespace dlaf_mi355x

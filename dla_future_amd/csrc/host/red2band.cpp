@@ -245,8 +245,8 @@ int reduction_to_band_device(DeviceMatrix<T>& A, int band, T* taus_host) {
       }
       // ---- 2. reflectors (xGEQR2 without the size-1 reflector) ---------------------------------------------------
       bool t_ready = false;
-      if constexpr (!TypeInfo<T>::is_complex) {
-        if (blocked_any && panel_qr_blocked_supported(b, m, nr, sizeof(T), false)) {
+      if constexpr (!std::is_same_v<T, cfloat>) {  // (the small kernels are instantiated for float, double, cdouble)
+        if (blocked_any && panel_qr_blocked_supported(b, m, nr, sizeof(T), TypeInfo<T>::is_complex)) {
           // CholeskyQR2 on the column-major copy, then the Householder reconstruction (kernels_hr.hip).  Every kernel
           // behind the first factorization looks at hr_flag and does nothing once it is raised.
           T* P = Pcm;

@@ -11,7 +11,11 @@ inline T* tm_dev_alloc(size_t elems) {
   T* p = nullptr;
   if (elems == 0)
     elems = 1;
-  DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), elems * sizeof(T)));
+  if (hipMalloc(reinterpret_cast<void**>(&p), elems * sizeof(T)) != hipSuccess) {
+    (void) hipGetLastError();
+    pool_release();  // (the workspace pool of the eigensolver stages may be holding what this allocation needs)
+    DLAF_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), elems * sizeof(T)));
+  }
   return p;
 }
 

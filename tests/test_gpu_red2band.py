@@ -85,14 +85,15 @@ def test_reduction_to_band_fast_path_sizes(dlaf, grid, rb, oracle, t, n, nb, ban
 
 
 def test_reduction_to_band_blocked_panels_and_their_gate(dlaf, grid, rb, oracle):
-    """fp64 panels of band 64 / 128 take the blocked factorization (CholeskyQR2 + Householder reconstruction,
+    """Double-precision panels (real and complex) of band 64 / 128 take the blocked factorization (CholeskyQR2 + Householder reconstruction,
     csrc/device/kernels_hr.hip) and must give xGEQR2's reflectors, taus and R element by element (run_and_check compares
     with the oracle's reflector-by-reflector restatement); panels whose Gram matrix is singular or badly conditioned are
     handed back to the reflector-by-reflector kernel by the gate -- same checks."""
-    for n, nb, band in [(2048, 512, 128), (1100, 256, 128), (700, 128, 64)]:
-        run_and_check(dlaf, grid, rb, oracle, "d", n, nb, band, False)
+    for t, n, nb, band in [("d", 2048, 512, 128), ("d", 1100, 256, 128), ("d", 700, 128, 64), ("z", 1100, 256, 128),
+                           ("z", 700, 128, 64)]:
+        run_and_check(dlaf, grid, rb, oracle, t, n, nb, band, False)
         blocked, fallback = dlaf.red2band_panel_stats()
-        assert blocked > 0 and fallback == 0, (n, nb, band, blocked, fallback)
+        assert blocked > 0 and fallback == 0, (t, n, nb, band, blocked, fallback)
     # the identity matrix: every panel is zero below the band (test_eigensolver.cpp:72-76 runs it end to end)
     n, nb, band = 1024, 256, 128
     a = np.asfortranarray(np.eye(n))
