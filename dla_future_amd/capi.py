@@ -14,7 +14,8 @@ class LibraryNotBuilt(RuntimeError):
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "lib", "libdlaf_mi355x.so")
+    # DLAF_MI355X_LIB: another build of the same library (diagnosis builds, e.g. tools/run_b2t_phases.sh)
+    return os.environ.get("DLAF_MI355X_LIB") or os.path.join(_HERE, "lib", "libdlaf_mi355x.so")
 
 
 class DLAFDescriptor(C.Structure):

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(kB2tThreads) void b2t_kernel(B2tArgs<T> p) {
       if (tid == 0) {
         unsigned v;
         long spins = 0;
-        while ((v = __hip_atomic_load(p.progress + (s - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
+        while ((v = __hip_atomic_load(p.progress + (s - 1) * kB2tProgressStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
           __builtin_amdgcn_s_sleep(2);
           if (++spins > p.spin_limit ||
               ((spins & 255) == 0 && __hip_atomic_load(p.failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kB2tThreads) void b2t_kernel(B2tArgs<T> p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0)
-        __hip_atomic_store(p.progress + s, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.progress + s * kB2tProgressStride, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     bool ok = wait_prev(1u);
     // ---- start_sweep: the reflector that annihilates column s below the first sub-diagonal -----------------------
@@ -571,8 +571,24 @@ __device__ __forceinline__ int wave_reduce16_index(int lane) {
   return ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
 }
 
-// EARLY (band == kB2tRegBand): the loads of a step are issued before the wait for the predecessor's latest step, its
-// last column re-read after it (see the load section)
+// EARLY (band == kB2tRegBand): the loads of a step are issued before the wait for the predecessor's first column of
+// its next step, which is this step's last column (see the load section)
+// DLAF_MI355X_B2T_PROF (compile-time, tools/run_b2t_phases.sh): thread 0 of workgroup 0 accumulates the shader clock
+// between the marks of a step and prints the totals when the workgroup leaves
+#ifdef DLAF_MI355X_B2T_PROF
+#define B2T_MARK(i)                                                   \
+  do {                                                                \
+    if (tid == 0) {                                                   \
+      const unsigned long long now_ = __builtin_readcyclecounter();   \
+      Lprof[i] += now_ - Lprof[15];                                   \
+      Lprof[15] = now_;                                               \
+    }                                                                 \
+  } while (0)
+#else
+#define B2T_MARK(i) \
+  do {              \
+  } while (0)
+#endif
 template <class T, int NT, bool EARLY>
 __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
   using R = real_t<T>;
@@ -590,115 +606,163 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
   T* Lsc = Lzw + (size_t) NW * kB2tExt;   // [0] tau, [1] tau2, [2] alpha, [3] beta
   T* Lred = Lsc + 4;                      // NW x CPW: column totals of a wave's reductions
   unsigned* Lslot = reinterpret_cast<unsigned*>(Lred + NW * CPW);
+  unsigned* Lfail = Lslot + 1;            // raised when wave 0 gave up waiting: all waves leave at the next barrier
+  unsigned* Lseen = Lslot + 2;            // the predecessor's progress word as wave 0 last saw it
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long n = p.n;
+#ifdef DLAF_MI355X_B2T_PROF
+  __shared__ unsigned long long Lprof[16];
+  if (tid < 16)
+    Lprof[tid] = 0;
+  __syncthreads();
+  const unsigned long long prof_t0 = wall_clock64();
+#endif
+  if (tid == 0)
+    *Lfail = 0u;  // (the first barrier of the sweep loop orders it)
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc(p.band, 0, (int) ((size_t) (n + 2) * ldb * sizeof(T)), 0x00020000);
 
   for (;;) {
-    if (tid == 0)
+    if (tid == 0) {
       *Lslot = __hip_atomic_fetch_add(p.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *Lseen = 0u;
+    }
     __syncthreads();
-    const long s = (long) *Lslot;
+    const long s = (long) __builtin_amdgcn_readfirstlane((int) *Lslot);  // (scalar: everything derived from it stays in SGPRs)
     __syncthreads();
     if (s >= p.nsweeps)
       break;
-    auto wait_prev = [&](unsigned need) -> bool {
-      if (s == 0) {
-        __syncthreads();
-        return true;
-      }
-      if (tid == 0) {
-        unsigned v;
+#ifdef DLAF_MI355X_B2T_PROF
+    if (tid == 0)
+      Lprof[15] = __builtin_readcyclecounter();
+#endif
+    // progress[s] counts 2 per finished step, + 1 once the FIRST COLUMN of the step under way is final (see below).
+    // Wave 0 polls it, with scalar loads past the scalar cache (invalidate + glc): counted by lgkmcnt, they do not queue
+    // behind the block loads the wave has in flight (a vector load would return behind them).  What it sees goes into an
+    // LDS word on which the other waves spin: no barrier, one poller per workgroup on the L2.  When wave 0 gives up it
+    // raises Lfail and lets the others through; the waves leave together at the next barrier.
+    unsigned seen = 0u;  // (per wave: the last value read)
+    auto wave_wait = [&](unsigned need) {
+      if (s == 0 || seen >= need)
+        return;
+      if (wave == 0) {
+        const unsigned* prev = p.progress + (s - 1) * kB2tProgressStride;
         long spins = 0;
-        while ((v = __hip_atomic_load(p.progress + (s - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
+        unsigned r;
+        for (;;) {
+          asm volatile("s_dcache_inv\n\ts_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(prev) : "memory");
+          if (r >= need)
+            break;
           __builtin_amdgcn_s_sleep(1);
           if (++spins > p.spin_limit ||
               ((spins & 255) == 0 && __hip_atomic_load(p.failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-            v = 0xFFFFFFFFu;
+            if (lane == 0)
+              __hip_atomic_store(Lfail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            r = 0xFFFFFFFFu;
             break;
           }
         }
-        *Lslot = v;
+        seen = r;
+        if (lane == 0)
+          __hip_atomic_store(Lseen, r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
-      __syncthreads();
-      const unsigned r = *Lslot;
-      __syncthreads();
+      else {
+        unsigned r;
+        while ((r = (unsigned) __builtin_amdgcn_readfirstlane(
+                    (int) __hip_atomic_load(Lseen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) < need)
+          __builtin_amdgcn_s_sleep(1);
+        seen = r;
+      }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      return r != 0xFFFFFFFFu;
+    };
+    auto gave_up = [&]() -> bool {  // (behind a barrier: the same answer in every wave)
+      return __hip_atomic_load(Lfail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;
     };
     auto publish = [&](unsigned value) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0)
-        __hip_atomic_store(p.progress + s, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.progress + s * kB2tProgressStride, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
-    bool ok = wait_prev(1u);
+    // the first reflector of the sweep: column s, the first column of the predecessor's first block
+    wave_wait(1u);
+    int bdiv = b;  // (opaque: the reciprocal of the division is formed per sweep instead of living in a register)
+    asm volatile("" : "+s"(bdiv));
+    const long sblk = (long) ((int) s / bdiv);
     const bool cx_last = TypeInfo<T>::is_complex && s == n - 2;
     const int nsteps = cx_last ? 1 : (int) ((n - s - 2 + b - 1) / b);
-    if (ok) {
+    bool ok;
+    {
       const int nn = (int) (n - s - 1 < b ? n - s - 1 : b);
       T* col = p.band + s * ldb + 1;
-      for (int i = tid; i < kB2tExt; i += NT)
+      int td = tid;  // (opaque: the addresses derived from the thread index are formed here, not kept across the sweeps)
+      asm volatile("" : "+v"(td));
+      for (int i = td; i < kB2tExt; i += NT)
         Lv[i] = i < nn ? ld_sc(col + i) : zero_el<T>();
       __syncthreads();
-      if (wave == 0) {
+      ok = !gave_up();
+      if (ok && wave == 0) {
+        const int l0 = td & 63;
         T tau, beta;
-        wave_larfg(Lv, nn, lane, tau, beta);
-        if (lane == 0)
+        wave_larfg(Lv, nn, l0, tau, beta);
+        if (l0 == 0)
           Lsc[0] = tau;
-        for (int i = lane; i < nn; i += 64)
+        for (int i = l0; i < nn; i += 64)
           st_wt(col + i, i == 0 ? beta : zero_el<T>());
       }
       __syncthreads();
     }
+    // The block of a step lives in A: element (r, cc) at band[(j + cc) ldb + r - cc].  Sweep s - 1 is done with all of
+    // it but the last column when it has finished its step of the same number; the last column (cc = b - 1, rows from
+    // b - 1 on) is the FIRST column of the predecessor's next block, which that step finishes early: its rows over the
+    // diagonal block are final after the two-sided update, its rows below become (beta, 0, ..., 0) -- known as soon as
+    // the next reflector is.  The predecessor stores that column and publishes it right there, a third of a step before
+    // its other stores are out, and never touches it again.
+    T A[CPW][QN];
+    auto load_columns = [&](unsigned base, int wvv, int k0, int k1) {
+#pragma unroll
+      for (int k = 0; k < CPW; ++k) {
+        if (k >= k0 && k < k1) {
+          const int cc = wvv + NW * k;
+#pragma unroll
+          for (int q = 0; q < QN; ++q)
+            A[k][q] = buf_load_sc1<T>(rsrc, base + (unsigned) (64 * q * (int) sizeof(T)),
+                                      (unsigned) (cc * (ldb - 1) * (int) sizeof(T)));
+        }
+      }
+    };
     for (int step = 0; step < nsteps && ok; ++step) {
       const long j = 1 + s + (long) step * b;
       const int nh = (int) (n - j < b ? n - j : b);
       const long mrem = n - b - j;
       const int m = (int) (mrem < 0 ? 0 : (mrem < b ? mrem : b));
       const int rows = nh + m;
-      const T tau = Lsc[0];
-      {
-        const long pos = (s / b + step) * (long) b;
-        T* dst = p.vout + pos + s * p.ldv;
-        for (int i = tid; i < nh; i += NT)
-          dst[i] = i == 0 ? tau : Lv[i];
-      }
+      B2T_MARK(0);  // (sweep start / the tail of the previous step)
       // (the lane index is made opaque per step: otherwise the per-element masks and offsets are hoisted out of the
       //  step loop and kept alive across it)
       int ln = lane;
       asm volatile("" : "+v"(ln));
-      // ---- the block: all loads of the step; element (r, cc) lives at band[(j + cc) ldb + r - cc].  Of the block only
-      //      its last column (cc = b - 1, rows from b - 1 on: the first column of the predecessor's NEXT diagonal block) is
-      //      still being written by sweep s - 1 at its step + 1; everything else was final when the predecessor published
-      //      step + 1 finished steps -- which this sweep already waited for at its previous step (or at the sweep start).
-      //      So all columns but that one are loaded BEFORE the wait for step + 2: their latency hides behind it.
-      T A[CPW][QN];
+      int wv = wave;  // (and the wave index, with everything derived from it: column numbers, their offsets, LDS rows)
+      asm volatile("" : "+s"(wv));
+      const T tau = Lsc[0];  // (the barrier of the previous publish orders wave 0's hand-over of reflector and tau)
+      {
+        T* dst = p.vout + (sblk + step) * (long) b + s * p.ldv;
+        const int i = ln + 64 * wv;
+        if (i < nh)
+          dst[i] = i == 0 ? tau : Lv[i];
+      }
       const unsigned base_off = (unsigned) ((j * ldb + ln) * (long) sizeof(T));
-      if constexpr (EARLY) {
-#pragma unroll
-        for (int k = 0; k < CPW; ++k) {
-          const int cc = wave + NW * k;
-#pragma unroll
-          for (int q = 0; q < QN; ++q)
-            A[k][q] = buf_load_sc1<T>(rsrc, base_off + (unsigned) (64 * q * (int) sizeof(T)),
-                                      (unsigned) (cc * (ldb - 1) * (int) sizeof(T)));
-        }
-      }
-      ok = wait_prev((unsigned) step + 2u);
-      if (!ok)
-        break;
-#pragma unroll
-      for (int k = EARLY ? CPW - 1 : 0; k < CPW; ++k) {
-        // (EARLY: column b - 1 = wave NW - 1, k = CPW - 1; the other waves re-read a column that was final already)
-        const int cc = wave + NW * k;
-#pragma unroll
-        for (int q = 0; q < QN; ++q)
-          A[k][q] = buf_load_sc1<T>(rsrc, base_off + (unsigned) (64 * q * (int) sizeof(T)),
-                                    (unsigned) (cc * (ldb - 1) * (int) sizeof(T)));
-      }
+      // ---- the block.  EARLY: all columns but the last are loaded as soon as the predecessor has finished this step
+      //      (as a rule long ago), their latency hides behind the wait for its first column of the next
+      wave_wait(2u * (unsigned) step + 2u);
+      if constexpr (EARLY)
+        load_columns(base_off, wv, 0, CPW - 1);
+      B2T_MARK(1);
+      wave_wait(2u * (unsigned) step + 3u);
+      B2T_MARK(2);  // wait for the predecessor
+      // (EARLY: column b - 1 = wave NW - 1, k = CPW - 1; the other waves read a column that was final already)
+      load_columns(base_off, wv, EARLY ? CPW - 1 : 0, CPW);
       T vr[QN], zacc[QN];
 #pragma unroll
       for (int q = 0; q < QN; ++q) {
@@ -713,7 +777,7 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
           const int k = half * 8 + kk;
-          const int cc = wave + NW * k;
+          const int cc = wv + NW * k;
           const T vc = Lv[cc];  // (zero beyond the reflector)
           T part = zero_el<T>();
 #pragma unroll
@@ -732,14 +796,20 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
           }
           parts[kk] = part;
         }
-        const T tot = wave_reduce8(parts, lane);
-        if ((lane & 7) == 0)
-          Lcs[wave + NW * (half * 8 + wave_reduce8_index(lane))] = tot;
+        const T tot = wave_reduce8(parts, ln);
+        if ((ln & 7) == 0)
+          Lcs[wv + NW * (half * 8 + wave_reduce8_index(ln))] = tot;
       }
 #pragma unroll
       for (int q = 0; q < QN; ++q)
-        Lzw[(size_t) wave * kB2tExt + ln + 64 * q] = zacc[q];
+        Lzw[(size_t) wv * kB2tExt + ln + 64 * q] = zacc[q];
+      B2T_MARK(3);  // last column + P1
       __syncthreads();
+      if (gave_up()) {
+        ok = false;
+        break;
+      }
+      B2T_MARK(4);  // barrier
       // ---- P2 (every wave for itself: no workgroup barrier): wx = [tau (z + cs) - 1/2 tau (w^H v) v ; tau B v ; 0] over
       //      the wave's own four rows per lane; w over the diagonal block also goes to the wave's LDS copy, from which the
       //      column operands conj(w_c) are broadcast
@@ -763,7 +833,7 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
         }
         const T dot = wave_sum_t(dotp);
         const T alpha = c_scale(c_mul(dot, tau), R(-0.5));
-        T* wd = Lwd + (size_t) wave * kB2tExt;
+        T* wd = Lwd + (size_t) wv * kB2tExt;
 #pragma unroll
         for (int q = 0; q < QN; ++q) {
           const int r = ln + 64 * q;
@@ -776,7 +846,7 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
         // ---- P3: A -= wx conj(v_c) + vx conj(w_c)  (two-sided update of D, right update of B) ---------------------------
 #pragma unroll
         for (int k = 0; k < CPW; ++k) {
-          const int cc = wave + NW * k;
+          const int cc = wv + NW * k;
           const T vcc = c_conj(Lv[cc]);
           const T wcc = c_conj(wd[cc]);
 #pragma unroll
@@ -789,14 +859,16 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
         }
       }
       // the first column of B is the next reflector's input (wave 0 holds column 0)
-      if (wave == 0) {
+      if (wv == 0) {
 #pragma unroll
         for (int q = 0; q < QN; ++q) {
           const int r = ln + 64 * q;
           Lv2[r] = (r >= nh && r < rows) ? A[0][q] : zero_el<T>();
         }
       }
+      B2T_MARK(5);  // P2 + P3
       __syncthreads();
+      B2T_MARK(6);  // barrier
       // ---- P4 (every wave for itself): the reflector of the first column of B, xLARFG on the wave's registers ---------
       T v2r[QN];
       T tau2 = zero_el<T>(), beta = zero_el<T>();
@@ -832,11 +904,29 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
             v2r[q] = m > 1 ? make_el<T>(R(1), R(0)) : zero_el<T>();  // (m <= 1: no reflector, nothing to apply)
         }
       }
-      // ---- P5/6: A -= v2x (conj(tau2) conj(A_c^H v2)) on the columns of B but the first, then all stores ------------------
+      // ---- the first column of the block is final: rows of D since P3, rows of B = (beta, 0, ..., 0).  Wave 0 holds it,
+      //      stores it and publishes it; the successor's step of the same number may start on it (m == 1: the element
+      //      itself, beta holds it)
+      asm volatile("" : "+v"(ln));
+      const unsigned base_st = (unsigned) ((j * ldb + ln) * (long) sizeof(T));
+      if (wv == 0) {
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+          const int r = ln + 64 * q;
+          T v = A[0][q];
+          if (r >= nh)
+            v = r == nh ? beta : zero_el<T>();
+          buf_store_sc1<T>(rsrc, r < rows ? base_st + (unsigned) (64 * q * (int) sizeof(T)) : kOob, 0u, v);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ln == 0)
+          __hip_atomic_store(p.progress + s * kB2tProgressStride, 2u * (unsigned) step + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      B2T_MARK(7);  // P4, first column out
+      // ---- P5/6: A -= v2x (conj(tau2) conj(A_c^H v2)) on the columns of B but the first, then the stores of all columns
+      //      but the first (which the successor may be changing by now)
       {
         const T ctau2 = c_conj(tau2);
-        asm volatile("" : "+v"(ln));
-        const unsigned base_st = (unsigned) ((j * ldb + ln) * (long) sizeof(T));
         {
           T parts[CPW];
 #pragma unroll
@@ -847,26 +937,22 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
               part = c_add(part, c_cmul(A[k][q], v2r[q]));
             parts[k] = part;
           }
-          const T tot = wave_reduce16(parts, lane);
-          if ((lane & 3) == 0)
-            Lred[wave * CPW + wave_reduce16_index(lane)] = tot;
+          const T tot = wave_reduce16(parts, ln);
+          if ((ln & 3) == 0)
+            Lred[wv * CPW + wave_reduce16_index(ln)] = tot;
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
 #pragma unroll
         for (int k = 0; k < CPW; ++k) {
-          const int cc = wave + NW * k;
-          const T f = c_mul(ctau2, c_conj(Lred[wave * CPW + k]));
+          const int cc = wv + NW * k;
+          const T f = c_mul(ctau2, c_conj(Lred[wv * CPW + k]));
 #pragma unroll
           for (int q = 0; q < QN; ++q) {
             const int r = ln + 64 * q;
-            T v = c_sub(A[k][q], c_mul(v2r[q], f));
-            if (wave == 0 && k == 0 && r >= nh) {
-              // first column of B: beta on top, exact zeros below (m == 1: the element itself, beta holds it)
-              v = r == nh ? beta : zero_el<T>();
-            }
-            const bool valid = cc < nh && r >= cc && r < rows;
+            const T v = c_sub(A[k][q], c_mul(v2r[q], f));
+            const bool valid = cc < nh && r >= cc && r < rows && cc != 0;
             buf_store_sc1<T>(rsrc, valid ? base_st + (unsigned) (64 * q * (int) sizeof(T)) : kOob,
                              (unsigned) (cc * (ldb - 1) * (int) sizeof(T)), v);
           }
@@ -874,20 +960,28 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
       }
       // the reflector of the next step (rows of B -> rows 0 .. m), written by wave 0; the barrier of publish() orders it
       if (m > 1) {
-        if (wave == 0) {
+        if (wv == 0) {
 #pragma unroll
           for (int q = 0; q < QN; ++q) {
             const int r = ln + 64 * q;
             if (r >= nh && r < rows)
               Lv[r - nh] = v2r[q];
             if (r >= m && r < kB2tExt && (r < nh || r >= rows))
-              Lv[r] = zero_el<T>();
+              Lv[r] = make_el<T>(R(ln >> 30), R(0));  // (zero, formed here: a constant would be kept -- spilled -- across the step)
           }
-          if (lane == 0)
+          if (ln == 0)
             Lsc[0] = tau2;
         }
       }
-      publish((unsigned) step + 1u);
+      B2T_MARK(8);  // P5, stores issued
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      B2T_MARK(9);  // stores acknowledged
+      publish(2u * (unsigned) step + 2u);
+      B2T_MARK(10);  // publish
+#ifdef DLAF_MI355X_B2T_PROF
+      if (tid == 0)
+        Lprof[14] += 1;
+#endif
     }
     if (!ok) {
       if (tid == 0) {
@@ -898,10 +992,20 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
     publish(kB2tDone);
     __syncthreads();
   }
+#ifdef DLAF_MI355X_B2T_PROF
+  if (tid == 0 && blockIdx.x == 0) {
+    const unsigned long long wall = wall_clock64() - prof_t0;  // 100 MHz
+    printf("[b2t phases] steps %llu wall %.3f ms; shader clocks per step:", Lprof[14], wall * 1e-5);
+    for (int i = 0; i <= 10; ++i)
+      printf(" [%d] %.0f", i, (double) Lprof[i] / (double) (Lprof[14] ? Lprof[14] : 1));
+    printf("\n");
+  }
+#endif
 }
+#undef B2T_MARK
 template <class T, int NT>
 size_t b2t_reg_lds_bytes() {
-  return ((size_t) 2 * kB2tExt + kB2tRegBand + (size_t) 2 * (NT / 64) * kB2tExt + 8 + kB2tRegBand) * sizeof(T) + 16;
+  return ((size_t) 2 * kB2tExt + kB2tRegBand + (size_t) 2 * (NT / 64) * kB2tExt + 8 + kB2tRegBand) * sizeof(T) + 16;  // (+ Lslot, Lfail, Lseen)
 }
 
 // ======================================================================================= reflector blocks

@@ -32,8 +32,11 @@ void launch_band_extract(const T* tiles, long ltr, int nb, int pr, int ri, int p
 // Afterwards d[i] = Re band[i * ldb], e[i] = Re band[i * ldb + 1] (launch_tridiag_extract).
 template <class T>
 void launch_band_to_tridiag(T* band, long n, int b, T* vout, long ldv, unsigned* sync, int* info, hipStream_t stream);
+// (a sweep's progress word has a 128-byte line to itself: pollers and publishers of neighbouring sweeps would
+//  otherwise meet in one L2 channel)
+constexpr int kB2tProgressStride = 32;
 inline size_t b2t_sync_words(long n) {
-  return (size_t) n + 64;
+  return (size_t) n * kB2tProgressStride + 64;
 }
 template <class T>
 void launch_tridiag_extract(const T* band, long n, int b, real_t<T>* d, real_t<T>* e, hipStream_t stream);
