@@ -769,37 +769,50 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
         vr[q] = Lv[ln + 64 * q];
         zacc[q] = zero_el<T>();
       }
+      // FULL: the block is 2 b x b with b = kB2tRegBand (every step but the last two of a sweep): the rows of a lane's
+      // upper two registers lie in D, those of the lower two in B, all of B is inside the block -- no masks there.  In
+      // every case the rows from kB2tRegBand on lie below the reflector: vr is zero there, and so is v2r above row nh.
+      const bool full = nh == kB2tRegBand && m == kB2tRegBand;
       // ---- P1: z = A v over the rows of both blocks, cs = strictly-lower(D)^H v -----------------------------------------
       static_assert(CPW == 16, "wave_reduce8 x 2 / wave_reduce16");
+      auto p1 = [&](auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        T parts[8];
+        for (int half = 0; half < 2; ++half) {
+          T parts[8];
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-          const int k = half * 8 + kk;
-          const int cc = wv + NW * k;
-          const T vc = Lv[cc];  // (zero beyond the reflector)
-          T part = zero_el<T>();
+          for (int kk = 0; kk < 8; ++kk) {
+            const int k = half * 8 + kk;
+            const int cc = wv + NW * k;
+            const T vc = Lv[cc];  // (zero beyond the reflector)
+            T part = zero_el<T>();
 #pragma unroll
-          for (int q = 0; q < QN; ++q) {
-            const int r = ln + 64 * q;
-            const bool valid = cc < nh && r >= cc && r < rows;
-            T a = valid ? A[k][q] : zero_el<T>();
-            if (64 * q < kB2tRegBand && r == cc)
-              a = make_el<T>(re_of(a), R(0));  // the diagonal element
-            A[k][q] = a;
-            zacc[q] = c_add(zacc[q], c_mul(a, vc));
-            if (64 * q < kB2tRegBand)
-              part = c_add(part, r == cc ? zero_el<T>() : c_cmul(a, vr[q]));
-            else
-              part = c_add(part, c_cmul(a, vr[q]));  // (rows of B: vr is zero there)
+            for (int q = 0; q < QN; ++q) {
+              const int r = ln + 64 * q;
+              T a = A[k][q];
+              if (64 * q < kB2tRegBand) {
+                const bool valid = FULL ? r >= cc : (cc < nh && r >= cc && r < rows);
+                a = valid ? a : zero_el<T>();
+                if (r == cc)
+                  a = make_el<T>(re_of(a), R(0));  // the diagonal element
+                A[k][q] = a;
+                part = c_add(part, r == cc ? zero_el<T>() : c_cmul(a, vr[q]));
+              }
+              else if (!FULL) {
+                a = (cc < nh && r < rows) ? a : zero_el<T>();  // (r >= cc holds)
+                A[k][q] = a;
+              }
+              zacc[q] = c_add(zacc[q], c_mul(a, vc));
+            }
+            parts[kk] = part;
           }
-          parts[kk] = part;
+          const T tot = wave_reduce8(parts, ln);
+          if ((ln & 7) == 0)
+            Lcs[wv + NW * (half * 8 + wave_reduce8_index(ln))] = tot;
         }
-        const T tot = wave_reduce8(parts, ln);
-        if ((ln & 7) == 0)
-          Lcs[wv + NW * (half * 8 + wave_reduce8_index(ln))] = tot;
-      }
+      };
+      // (a second instance of P1 for full blocks -- no masks on the rows of B -- costs 71 spilled registers: not taken)
+      p1(std::false_type{});
 #pragma unroll
       for (int q = 0; q < QN; ++q)
         Lzw[(size_t) wv * kB2tExt + ln + 64 * q] = zacc[q];
@@ -852,9 +865,13 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
 #pragma unroll
           for (int q = 0; q < QN; ++q) {
             const int r = ln + 64 * q;
-            const bool valid = r >= cc;  // (columns beyond the block have vcc = wcc = 0, rows beyond it wr = vr = 0)
-            const T upd = c_add(c_mul(wr[q], vcc), c_mul(vr[q], wcc));
-            A[k][q] = c_sub(A[k][q], valid ? upd : zero_el<T>());
+            // (columns beyond the block have vcc = wcc = 0, rows beyond it wr = vr = 0)
+            if (64 * q < kB2tRegBand) {
+              const T upd = c_add(c_mul(wr[q], vcc), c_mul(vr[q], wcc));
+              A[k][q] = c_sub(A[k][q], r >= cc ? upd : zero_el<T>());
+            }
+            else
+              A[k][q] = c_sub(A[k][q], c_mul(wr[q], vcc));  // (below the reflector)
           }
         }
       }
@@ -924,16 +941,31 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
       }
       B2T_MARK(7);  // P4, first column out
       // ---- P5/6: A -= v2x (conj(tau2) conj(A_c^H v2)) on the columns of B but the first, then the stores of all columns
-      //      but the first (which the successor may be changing by now)
-      {
+      //      but the first (which the successor may be changing by now).  FULL: v2 lives on the lower two registers, the
+      //      rows of D (final since P3) go out first, beside the reduction
+      auto p5 = [&](auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
+        constexpr int Q0 = FULL ? kB2tRegBand / 64 : 0;
         const T ctau2 = c_conj(tau2);
+        if constexpr (FULL) {
+#pragma unroll
+          for (int k = 0; k < CPW; ++k) {
+            const int cc = wv + NW * k;
+#pragma unroll
+            for (int q = 0; q < Q0; ++q) {
+              const int r = ln + 64 * q;
+              buf_store_sc1<T>(rsrc, (r >= cc && cc != 0) ? base_st + (unsigned) (64 * q * (int) sizeof(T)) : kOob,
+                               (unsigned) (cc * (ldb - 1) * (int) sizeof(T)), A[k][q]);
+            }
+          }
+        }
         {
           T parts[CPW];
 #pragma unroll
           for (int k = 0; k < CPW; ++k) {
             T part = zero_el<T>();
 #pragma unroll
-            for (int q = 0; q < QN; ++q)
+            for (int q = Q0; q < QN; ++q)
               part = c_add(part, c_cmul(A[k][q], v2r[q]));
             parts[k] = part;
           }
@@ -949,15 +981,21 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
           const int cc = wv + NW * k;
           const T f = c_mul(ctau2, c_conj(Lred[wv * CPW + k]));
 #pragma unroll
-          for (int q = 0; q < QN; ++q) {
+          for (int q = Q0; q < QN; ++q) {
             const int r = ln + 64 * q;
             const T v = c_sub(A[k][q], c_mul(v2r[q], f));
-            const bool valid = cc < nh && r >= cc && r < rows && cc != 0;
+            const bool valid = FULL ? cc != 0 : (cc < nh && r >= cc && r < rows && cc != 0);
             buf_store_sc1<T>(rsrc, valid ? base_st + (unsigned) (64 * q * (int) sizeof(T)) : kOob,
                              (unsigned) (cc * (ldb - 1) * (int) sizeof(T)), v);
           }
         }
-      }
+      };
+      if constexpr (TypeInfo<T>::is_complex)
+        p5(std::false_type{});  // (two instances do not fit the registers of the complex kernel)
+      else if (full)
+        p5(std::true_type{});
+      else
+        p5(std::false_type{});
       // the reflector of the next step (rows of B -> rows 0 .. m), written by wave 0; the barrier of publish() orders it
       if (m > 1) {
         if (wv == 0) {
