@@ -19,7 +19,8 @@ and a GPU and fails loudly otherwise.
 from .capi import (DLAFDescriptor, LibraryNotBuilt, lib, lib_path, type_char, version)  # noqa: F401
 from .cholesky import (DeviceMatrix, GeneralDeviceMatrix, Grid, cholesky_factorization, finalize, generalized_to_standard,  # noqa: F401
                        initialize, make_descriptor, potrf_trace, pxhegst, pxpotrf, pxpotrs, pxtrsm, set_random_hermitian_positive_definite, tile_gemm, tile_herk, tile_potrf,
-                       tile_trsm, triangular_solver, triangular_solver_device, potrs_device, solver_profile, update_launch_stats)
+                       tile_trsm, triangular_solver, triangular_solver_device, potrs_device, release_workspace_pool, solver_profile,
+                       update_launch_stats)
 from . import distribution  # noqa: F401
 from .eigensolver import (band_to_tridiagonal, bt_band_to_tridiagonal, bt_reduction_to_band,  # noqa: F401
                           bt_reduction_to_band_device, eigensolver_min_band, eigensolver_profile, get_band_size, hermitian_eigensolver,

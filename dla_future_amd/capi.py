@@ -163,6 +163,7 @@ SIGNATURES = {
     "dlaf_mi355x_eigensolver_profile": (_i, [C.POINTER(C.c_double)]),
     "dlaf_mi355x_get_band_size": (_i, [_i]),
     "dlaf_mi355x_red2band_panel_stats": (_i, [C.POINTER(C.c_long), C.POINTER(C.c_long)]),
+    "dlaf_mi355x_workspace_pool_release": (C.c_long, []),
     "dlaf_mi355x_get_eigensolver_min_band": (_i, []),
     "dlaf_mi355x_set_eigensolver_min_band": (None, [_i]),
     "dlaf_mi355x_red2band_profile": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -274,6 +274,12 @@ def potrf_trace():
     return list(out) if lib().dlaf_mi355x_potrf_trace(out) == 0 else None
 
 
+def release_workspace_pool() -> int:
+    """Give the idle blocks of the workspace pool back to the driver (dlaf_mi355x_workspace_pool_release); returns the bytes
+    that were held."""
+    return int(lib().dlaf_mi355x_workspace_pool_release())
+
+
 def update_launch_stats():
     """(persistent, exclusive): trailing-update launches of this process so far in persistent form / with exclusive
     compute units."""

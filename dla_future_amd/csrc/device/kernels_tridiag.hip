@@ -9,7 +9,9 @@
 //
 // MI355X design: ONE launch.  Persistent workgroups draw sweeps from a counter (so a workgroup only ever waits for
 // a sweep that some resident workgroup already owns: no co-residency assumption), sweep s runs step t once sweep
-// s - 1 has published t + 2 finished steps.  A step touches 1.5 b^2 elements of the band copy, which stays in the
+// s - 1 has published t + 2 finished steps (b2t_kernel) -- or, in the register kernel, once sweep s - 1 has finished
+// step t and published the FIRST COLUMN of its step t + 1, the only part of that step this one reads (b2t_reg_kernel:
+// the progress word counts 2 per step + 1 for that column).  A step touches 1.5 b^2 elements of the band copy, which stays in the
 // memory-side cache (42 MB at n = 20480, b = 128); the band bytes are handed from workgroup to workgroup, possibly on
 // another XCD, once per sweep: they are stored write-through and loaded sc1 (cdna_hip_programming.md, Guideline 16:
 // "every load sc1"), the progress word of a sweep is one relaxed agent-scope atomic.  Inside a step a wave owns a
@@ -719,16 +721,22 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
     // diagonal block are final after the two-sided update, its rows below become (beta, 0, ..., 0) -- known as soon as
     // the next reflector is.  The predecessor stores that column and publishes it right there, a third of a step before
     // its other stores are out, and never touches it again.
+    // An element outside the block (above the diagonal of D, beyond the matrix) is loaded from an out-of-range offset:
+    // the descriptor's bounds check returns zero without touching memory, and the phases need no masks.
     T A[CPW][QN];
-    auto load_columns = [&](unsigned base, int wvv, int k0, int k1) {
+    auto load_columns = [&](unsigned base, int lnn, int wvv, int nhh, int rws, int k0, int k1) {
 #pragma unroll
       for (int k = 0; k < CPW; ++k) {
         if (k >= k0 && k < k1) {
           const int cc = wvv + NW * k;
 #pragma unroll
-          for (int q = 0; q < QN; ++q)
-            A[k][q] = buf_load_sc1<T>(rsrc, base + (unsigned) (64 * q * (int) sizeof(T)),
+          for (int q = 0; q < QN; ++q) {
+            const int r = lnn + 64 * q;
+            // (rows from kB2tRegBand on lie below every column's diagonal)
+            const bool valid = cc < nhh && r < rws && (64 * q >= kB2tRegBand || r >= cc);
+            A[k][q] = buf_load_sc1<T>(rsrc, valid ? base + (unsigned) (64 * q * (int) sizeof(T)) : kOob,
                                       (unsigned) (cc * (ldb - 1) * (int) sizeof(T)));
+          }
         }
       }
     };
@@ -757,12 +765,12 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
       //      (as a rule long ago), their latency hides behind the wait for its first column of the next
       wave_wait(2u * (unsigned) step + 2u);
       if constexpr (EARLY)
-        load_columns(base_off, wv, 0, CPW - 1);
+        load_columns(base_off, ln, wv, nh, rows, 0, CPW - 1);
       B2T_MARK(1);
       wave_wait(2u * (unsigned) step + 3u);
       B2T_MARK(2);  // wait for the predecessor
       // (EARLY: column b - 1 = wave NW - 1, k = CPW - 1; the other waves read a column that was final already)
-      load_columns(base_off, wv, EARLY ? CPW - 1 : 0, CPW);
+      load_columns(base_off, ln, wv, nh, rows, EARLY ? CPW - 1 : 0, CPW);
       T vr[QN], zacc[QN];
 #pragma unroll
       for (int q = 0; q < QN; ++q) {
@@ -770,13 +778,12 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
         zacc[q] = zero_el<T>();
       }
       // FULL: the block is 2 b x b with b = kB2tRegBand (every step but the last two of a sweep): the rows of a lane's
-      // upper two registers lie in D, those of the lower two in B, all of B is inside the block -- no masks there.  In
-      // every case the rows from kB2tRegBand on lie below the reflector: vr is zero there, and so is v2r above row nh.
+      // upper two registers lie in D, those of the lower two in B.  In every case the rows from kB2tRegBand on lie
+      // below the reflector: vr is zero there, and so is v2r above row nh.
       const bool full = nh == kB2tRegBand && m == kB2tRegBand;
       // ---- P1: z = A v over the rows of both blocks, cs = strictly-lower(D)^H v -----------------------------------------
       static_assert(CPW == 16, "wave_reduce8 x 2 / wave_reduce16");
-      auto p1 = [&](auto full_c) {
-        constexpr bool FULL = decltype(full_c)::value;
+      {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
           T parts[8];
@@ -789,18 +796,15 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
 #pragma unroll
             for (int q = 0; q < QN; ++q) {
               const int r = ln + 64 * q;
-              T a = A[k][q];
+              T a = A[k][q];  // (zero outside the block: load_columns)
               if (64 * q < kB2tRegBand) {
-                const bool valid = FULL ? r >= cc : (cc < nh && r >= cc && r < rows);
-                a = valid ? a : zero_el<T>();
-                if (r == cc)
-                  a = make_el<T>(re_of(a), R(0));  // the diagonal element
-                A[k][q] = a;
+                if constexpr (TypeInfo<T>::is_complex) {
+                  if (r == cc) {
+                    a = make_el<T>(re_of(a), R(0));  // the diagonal element
+                    A[k][q] = a;
+                  }
+                }
                 part = c_add(part, r == cc ? zero_el<T>() : c_cmul(a, vr[q]));
-              }
-              else if (!FULL) {
-                a = (cc < nh && r < rows) ? a : zero_el<T>();  // (r >= cc holds)
-                A[k][q] = a;
               }
               zacc[q] = c_add(zacc[q], c_mul(a, vc));
             }
@@ -810,9 +814,7 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
           if ((ln & 7) == 0)
             Lcs[wv + NW * (half * 8 + wave_reduce8_index(ln))] = tot;
         }
-      };
-      // (a second instance of P1 for full blocks -- no masks on the rows of B -- costs 71 spilled registers: not taken)
-      p1(std::false_type{});
+      }
 #pragma unroll
       for (int q = 0; q < QN; ++q)
         Lzw[(size_t) wv * kB2tExt + ln + 64 * q] = zacc[q];

@@ -26,7 +26,7 @@ void launch_band_extract(const T* tiles, long ltr, int nb, int pr, int ri, int p
 // ------------------------------------------------------------------------------------------ band -> tridiagonal
 // All sweeps in ONE launch of persistent workgroups: a workgroup draws the next sweep from a counter and runs its
 // steps; step t of sweep s waits until sweep s - 1 has finished t + 2 steps (the counting semaphores of
-// mc.h:683-709).  Hand-offs between workgroups: write-through stores, sc1 loads, one progress word per sweep.
+// mc.h:683-709; the register kernel waits for step t and the first column of step t + 1, kernels_tridiag.hip).  Hand-offs between workgroups: write-through stores, sc1 loads, one progress word per sweep.
 //   vout (n x n, ldv): the compact reflectors, tau in the place of the leading 1 (band_to_tridiag.h:56-63)
 //   sync: b2t_sync_words(n) unsigned words, zeroed by the launcher
 // Afterwards d[i] = Re band[i * ldb], e[i] = Re band[i * ldb + 1] (launch_tridiag_extract).

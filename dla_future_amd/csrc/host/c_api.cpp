@@ -772,6 +772,11 @@ int dlaf_mi355x_red2band_panel_stats(long* blocked, long* fallback) noexcept {
   red2band_last_panels(blocked, fallback);
   return 0;
 }
+long dlaf_mi355x_workspace_pool_release(void) noexcept {
+  const long held = (long) pool_idle_bytes();
+  pool_release();
+  return held;
+}
 int dlaf_mi355x_get_eigensolver_min_band(void) noexcept {
   return eigensolver_min_band();
 }

@@ -149,6 +149,12 @@ void pool_release() {
     (void) hipFree(q);
 }
 
+size_t pool_idle_bytes() {
+  Pool& pl = pool();
+  std::lock_guard<std::mutex> lk(pl.mu);
+  return pl.idle_bytes;
+}
+
 bool runtime_initialized() {
   return g_initialized;
 }

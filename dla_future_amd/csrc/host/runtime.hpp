@@ -38,6 +38,7 @@ namespace dlaf_mi355x {
 hipError_t pool_malloc(void** p, size_t bytes);
 hipError_t pool_free(void* p);
 void pool_release();
+size_t pool_idle_bytes();
 
 // ------------------------------------------------------------------------------------------------
 // Transport: the broadcast primitive along a process row / column (communication/kernels/

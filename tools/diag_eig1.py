@@ -1,5 +1,7 @@
 """Diagnosis: the whole eigensolver on ONE process, same input, several runs: bitwise repeatable?"""
 import hashlib
+import time
+T0 = time.time()
 import os
 import sys
 
@@ -13,7 +15,9 @@ from oracle import tridiag as td
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 nb = 256
+T_IMPORT = time.time() - T0
 d.initialize()
+T_INIT = time.time() - T0
 g = d.Grid.single()
 a0 = rb.random_hermitian(n, np.float64, seed=700 + n)
 out = []
@@ -22,3 +26,4 @@ for r in range(reps):
     res = td.check_eigensolver(a0, w, z)
     out.append((hashlib.md5(z.tobytes()).hexdigest()[:8], f"{res['orth']:.1e}"))
 print(f"pid {os.getpid()} n={n}: {out}", flush=True)
+print(f"time pid {os.getpid()}: import {T_IMPORT:.1f} s, initialize at {T_INIT:.1f} s, all {time.time() - T0:.1f} s", flush=True)
