@@ -247,8 +247,7 @@ DLAF_EXTERN_C int dlaf_mi355x_bt_reduction_to_band_z(int context, int band_size,
 DLAF_EXTERN_C int dlaf_mi355x_red2band_panel_stats(long* blocked, long* fallback) DLAF_NOEXCEPT;
 /* Gives the idle blocks of the workspace pool back to the driver (the stages' temporaries of 4 MiB and more are kept between
  * calls, up to DLAF_MI355X_POOL_GB = 64 GiB; the analogue of the reference's Umpire pools, src/memory/memory_chunk.cpp,
- * which dlaf::finalize releases).  Returns the bytes that were held.  For a process that shares its GPU with others: a large
- * idle pool makes the OTHER processes' allocations and frees an order of magnitude slower on this stack. */
+ * which dlaf::finalize releases).  Returns the bytes that were held. */
 DLAF_EXTERN_C long dlaf_mi355x_workspace_pool_release(void) DLAF_NOEXCEPT;
 /* Tune parameter eigensolver_min_band (include/dlaf/tune.h:71-75,128; default 100).  dlaf_initialize reads
  * DLAF_EIGENSOLVER_MIN_BAND and --dlaf:eigensolver-min-band like src/init.cpp:220; the setter is what the reference's

@@ -31,8 +31,6 @@ def launch(mode, nprow, npcol, order, timeout, extra_env=None):
     if mode == "gpu":
         from conftest import gpu_process_budget
         gpu_process_budget(n)
-        import dla_future_amd as dlaf
-        dlaf.release_workspace_pool()   # (an idle pool in this process slows the ranks' allocations, test_gpu_race_screen.py)
     port = str(free_port())
     procs = []
     for rank in range(n):

@@ -10,17 +10,13 @@ import sys
 
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.fresh_parent]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def run_copies(script, args, copies, timeout):
     from conftest import gpu_process_budget
     gpu_process_budget(copies)
-    # this (idle) process may hold gigabytes of pooled workspaces from the tests before: every allocation and free of
-    # the copies is then ten times slower on this stack (26 s -> 280 s for the two tests of this file)
-    import dla_future_amd as dlaf
-    dlaf.release_workspace_pool()
     env = dict(os.environ, OMP_NUM_THREADS="1", DLAF_MI355X_DEVICE="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", script)] + [str(a) for a in args], cwd=ROOT, env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(copies)]
