@@ -573,6 +573,9 @@ __device__ __forceinline__ int wave_reduce16_index(int lane) {
   return ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
 }
 
+#ifndef DLAF_B2T_NOSLEEP
+#define DLAF_B2T_NOSLEEP 0
+#endif
 // EARLY (band == kB2tRegBand): the loads of a step are issued before the wait for the predecessor's first column of
 // its next step, which is this step's last column (see the load section)
 // DLAF_MI355X_B2T_PROF (compile-time, tools/run_b2t_phases.sh): thread 0 of workgroup 0 accumulates the shader clock
@@ -656,7 +659,9 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
           asm volatile("s_dcache_inv\n\ts_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(prev) : "memory");
           if (r >= need)
             break;
+#if !(DLAF_B2T_NOSLEEP & 1)
           __builtin_amdgcn_s_sleep(1);
+#endif
           if (++spins > p.spin_limit ||
               ((spins & 255) == 0 && __hip_atomic_load(p.failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
             if (lane == 0)
@@ -672,8 +677,11 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
       else {
         unsigned r;
         while ((r = (unsigned) __builtin_amdgcn_readfirstlane(
-                    (int) __hip_atomic_load(Lseen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) < need)
+                    (int) __hip_atomic_load(Lseen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) < need) {
+#if !(DLAF_B2T_NOSLEEP & 2)
           __builtin_amdgcn_s_sleep(1);
+#endif
+        }
         seen = r;
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -722,7 +730,9 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
     // the next reflector is.  The predecessor stores that column and publishes it right there, a third of a step before
     // its other stores are out, and never touches it again.
     // An element outside the block (above the diagonal of D, beyond the matrix) is loaded from an out-of-range offset:
-    // the descriptor's bounds check returns zero without touching memory, and the phases need no masks.
+    // the descriptor's bounds check returns zero without touching memory, and the phases need no masks.  (The complex
+    // instance, short of registers, is faster with the masks in P1: 329 against 361 ms at n = 12288.)
+    constexpr bool kMaskInP1 = TypeInfo<T>::is_complex;
     T A[CPW][QN];
     auto load_columns = [&](unsigned base, int lnn, int wvv, int nhh, int rws, int k0, int k1) {
 #pragma unroll
@@ -733,7 +743,7 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
           for (int q = 0; q < QN; ++q) {
             const int r = lnn + 64 * q;
             // (rows from kB2tRegBand on lie below every column's diagonal)
-            const bool valid = cc < nhh && r < rws && (64 * q >= kB2tRegBand || r >= cc);
+            const bool valid = kMaskInP1 || (cc < nhh && r < rws && (64 * q >= kB2tRegBand || r >= cc));
             A[k][q] = buf_load_sc1<T>(rsrc, valid ? base + (unsigned) (64 * q * (int) sizeof(T)) : kOob,
                                       (unsigned) (cc * (ldb - 1) * (int) sizeof(T)));
           }
@@ -797,6 +807,11 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
             for (int q = 0; q < QN; ++q) {
               const int r = ln + 64 * q;
               T a = A[k][q];  // (zero outside the block: load_columns)
+              if constexpr (kMaskInP1) {
+                const bool valid = cc < nh && r < rows && (64 * q >= kB2tRegBand || r >= cc);
+                a = valid ? a : zero_el<T>();
+                A[k][q] = a;
+              }
               if (64 * q < kB2tRegBand) {
                 if constexpr (TypeInfo<T>::is_complex) {
                   if (r == cc) {
