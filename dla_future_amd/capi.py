@@ -14,7 +14,7 @@ class LibraryNotBuilt(RuntimeError):
 
 
 def lib_path() -> str:
-    # DLAF_MI355X_LIB: another build of the same library (diagnosis builds, e.g. tools/run_b2t_phases.sh)
+    # DLAF_MI355X_LIB: another build of the same library (diagnosis builds, e.g. tools/build_b2t_prof.sh)
     return os.environ.get("DLAF_MI355X_LIB") or os.path.join(_HERE, "lib", "libdlaf_mi355x.so")
 
 

@@ -575,7 +575,7 @@ __device__ __forceinline__ int wave_reduce16_index(int lane) {
 
 // EARLY (band == kB2tRegBand): the loads of a step are issued before the wait for the predecessor's first column of
 // its next step, which is this step's last column (see the load section)
-// DLAF_MI355X_B2T_PROF (compile-time, tools/run_b2t_phases.sh): thread 0 of workgroup 0 accumulates the shader clock
+// DLAF_MI355X_B2T_PROF (compile-time, tools/build_b2t_prof.sh): thread 0 of workgroup 0 accumulates the shader clock
 // between the marks of a step and prints the totals when the workgroup leaves
 #ifdef DLAF_MI355X_B2T_PROF
 #define B2T_MARK(i)                                                   \
