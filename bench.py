@@ -82,7 +82,7 @@ def cpu_baseline(args):
     return out
 
 
-def red2band_line(dlaf, grid, n, nb, runs=2):
+def red2band_line(dlaf, grid, n, nb, runs=2, mats=None):
     """SURVEY.md 8(f)4 / BASELINE configs[4], first stage on one GPU: reduction_to_band of a random Hermitian matrix
     (the reference's set_random_hermitian = the SPD generator without the 2 n on the diagonal) resident in HBM, band =
     get_band_size(nb) as the reference's eigensolver picks it; flop model of miniapp_reduction_to_band.cpp:163-168.
@@ -91,8 +91,8 @@ def red2band_line(dlaf, grid, n, nb, runs=2):
     a = np.zeros((n, n), dtype=np.float64, order="F")
     dlaf.set_random_hermitian_positive_definite(grid, a, n, nb)
     a[np.arange(n), np.arange(n)] -= 2.0 * n
-    ref = dlaf.DeviceMatrix(grid, np.float64, "L", n, nb)
-    work = dlaf.DeviceMatrix(grid, np.float64, "L", n, nb)
+    ref, work = mats if mats is not None else (dlaf.DeviceMatrix(grid, np.float64, "L", n, nb),
+                                               dlaf.DeviceMatrix(grid, np.float64, "L", n, nb))
     ref.upload(a)
     del a
     best_ms = None
@@ -209,6 +209,13 @@ def main():
     a = np.zeros((max(1, lrows), max(1, lcols)), dtype=dt, order="F")[:lrows, :lcols]
     dlaf.set_random_hermitian_positive_definite(grid, a, n, nb)
     t_gen = time.perf_counter() - t_gen
+    # The two matrices of the reduction_to_band line are allocated FIRST: device memory handed out after the release of
+    # the factorization's 137 GB is slower on this stack -- the same stage 407 ms on matrices allocated behind that release,
+    # 344 ms on matrices allocated before it or in a fresh process (tools/diag_r2b_after_alloc.py)
+    r2b_mats = None
+    if world == 1 and not args.no_red2band and args.type == "d":
+        r2b_mats = (dlaf.DeviceMatrix(grid, np.float64, "L", args.r2b_n, args.r2b_nb),
+                    dlaf.DeviceMatrix(grid, np.float64, "L", args.r2b_n, args.r2b_nb))
     ref = dlaf.DeviceMatrix(grid, dt, args.uplo, n, nb)
     t_up = time.perf_counter()
     ref.upload(a)
@@ -352,16 +359,13 @@ def main():
                 ref.close()
             except Exception:
                 pass
-            # (the whole solver first: right behind the factorization -- and the release of its 100 GB -- the stage alone
-            #  has been measured 10 - 20 % slower than inside the solver a few seconds later, 27 against 32 TFlop/s, in the
-            #  same process; alone in a process, or behind a factorization in tools/diag_r2b_after_chol.py, it is not)
             if not args.no_eigensolver:
                 try:
                     line["eigensolver"] = eigensolver_line(dlaf, grid, args.r2b_n, args.r2b_nb)
                 except Exception as e:
                     line["eigensolver"] = {"value": None, "error": repr(e)}
             try:
-                line["reduction_to_band"] = red2band_line(dlaf, grid, args.r2b_n, args.r2b_nb, runs=3)
+                line["reduction_to_band"] = red2band_line(dlaf, grid, args.r2b_n, args.r2b_nb, runs=3, mats=r2b_mats)
             except Exception as e:  # an extra line: it must never take the metric down with it
                 line["reduction_to_band"] = {"value": None, "error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
