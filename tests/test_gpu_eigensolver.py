@@ -89,6 +89,47 @@ def test_band_to_tridiag_many_sweeps_in_flight(dlaf, grid, td, t, n, nb, band):
     assert np.abs(rd - d).max() <= tol and np.abs(np.abs(re_) - np.abs(e)).max() <= tol, (np.abs(rd - d).max(), tol)
 
 
+B2T_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import dla_future_amd as d
+d.initialize()
+g = d.Grid.single()
+n, nb, band = 1100, 256, 128
+rng = np.random.default_rng(5)
+a = np.zeros((n, n), order="F")
+for k in range(band + 1):
+    a[np.arange(k, n), np.arange(0, n - k)] = rng.uniform(-1, 1, n - k)
+dd, ee, v = d.band_to_tridiagonal(g, a, nb, band)
+import scipy.linalg as sl
+ab = np.zeros((band + 1, n))
+for k in range(band + 1):
+    ab[k, :n - k] = a[np.arange(k, n), np.arange(0, n - k)]
+print("RESULT", np.abs(sl.eigvals_banded(ab, lower=True) - sl.eigvalsh_tridiagonal(dd, ee)).max(), flush=True)
+"""
+
+
+def test_band_to_tridiag_expired_wait_is_reported_not_hung():
+    """DLAF_MI355X_B2T_SPIN_LIMIT=0: the first wait of a sweep for its predecessor that is not satisfied at once gives up.
+    The register kernel's waves poll without a barrier (wave 0 the progress word, the others an LDS word), so the give-up
+    path -- raise a flag, let every wave through, leave together at the next barrier, publish the sweep as done -- must drain
+    the launch; the host refuses the result loudly, and the device is usable afterwards."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def child(**env):
+        return subprocess.run([sys.executable, "-c", B2T_CHILD % root], cwd=root, env=dict(os.environ, **env),
+                              capture_output=True, text=True, timeout=300)
+    r = child(DLAF_MI355X_B2T_SPIN_LIMIT="0")
+    assert r.returncode != 0, r.stdout
+    assert "gave up waiting for its predecessor" in r.stderr, r.stderr[-3000:]
+    r = child()
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    assert float([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1].split()[1]) <= 1100 * 2.3e-16 * 200, r.stdout
+
+
 @pytest.mark.parametrize("t", ["d", "s"])
 def test_tridiagonal_eigensolver_laplace_1d(dlaf, td, t):
     dt = DT[t]
