@@ -80,17 +80,10 @@ __device__ __forceinline__ real_t<T> c_abs2(const T& a) {
 }
 
 template <class T>
+__device__ __forceinline__ T wave_sum_fast(T v);  // (DPP + permlane swaps, below: no trip through the LDS crossbar)
+template <class T>
 __device__ __forceinline__ T wave_sum_t(T v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    if constexpr (TypeInfo<T>::is_complex) {
-      v.re += __shfl_xor(v.re, off);
-      v.im += __shfl_xor(v.im, off);
-    }
-    else
-      v += __shfl_xor(v, off);
-  }
-  return v;
+  return wave_sum_fast(v);
 }
 
 // write-through store / sc1 load of one element (relaxed agent-scope atomics on its 4- or 8-byte words)
@@ -506,65 +499,127 @@ __device__ __forceinline__ void buf_store_sc1(__amdgpu_buffer_rsrc_t rsrc, unsig
   }
 }
 
-// Sums of 16 values per lane over the 64 lanes of a wave in 17 lane exchanges instead of 16 x 6: at every stage a
-// lane keeps half of its values and sends the other half to its partner (lane ^ 32, 16, 8, 4), then two plain stages.
-// On return lane l holds the total of value index ((l >> 5) & 1) * 8 + ((l >> 4) & 1) * 4 + ((l >> 3) & 1) * 2 + ((l >> 2) & 1).
-template <class T>
-__device__ __forceinline__ T shfl_xor_t(const T& v, int mask) {
-  if constexpr (TypeInfo<T>::is_complex)
-    return T{__shfl_xor(v.re, mask), __shfl_xor(v.im, mask)};
-  else
-    return __shfl_xor(v, mask);
+// Lane exchanges without the LDS crossbar (ds_bpermute: an address register and ~50 clocks of latency per exchange, and
+// two selects per word to pick what to send): gfx950's v_permlane32_swap / v_permlane16_swap trade the upper half (the
+// odd rows) of one register against the lower half (the even rows) of another -- exactly the "keep half, send half"
+// step of a transposing reduction, in one instruction per word and no select -- and DPP row controls reach the partner
+// inside a row of 16 (profiles/r04_permlane_probe.txt has the lane maps).
+template <class R, class F>
+__device__ __forceinline__ R words_map(const R& x, F f) {
+  constexpr int W = (int) sizeof(R) / 4;
+  struct Wd {
+    unsigned w[W];
+  };
+  Wd v = __builtin_bit_cast(Wd, x);
+#pragma unroll
+  for (int i = 0; i < W; ++i)
+    v.w[i] = f(v.w[i]);
+  return __builtin_bit_cast(R, v);
 }
+template <int CTRL, class R>
+__device__ __forceinline__ R dpp_real(const R& x) {
+  return words_map(x, [](unsigned w) { return (unsigned) __builtin_amdgcn_update_dpp(0u, w, CTRL, 0xf, 0xf, false); });
+}
+template <int CTRL, class T>
+__device__ __forceinline__ T dpp_t(const T& v) {
+  if constexpr (TypeInfo<T>::is_complex)
+    return T{dpp_real<CTRL>(v.re), dpp_real<CTRL>(v.im)};
+  else
+    return dpp_real<CTRL>(v);
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppRor8 = 0x128;  // quad_perm [1,0,3,2] / [2,3,0,1]
+// a <- [a.lo32 | b.lo32], b <- [a.hi32 | b.hi32]  (ROWS = false);  a <- rows [a0 b0 a2 b2], b <- rows [a1 b1 a3 b3]  (true)
+template <bool ROWS, class R>
+__device__ __forceinline__ void swap_real(R& a, R& b) {
+  constexpr int W = (int) sizeof(R) / 4;
+  struct Wd {
+    unsigned w[W];
+  };
+  Wd x = __builtin_bit_cast(Wd, a), y = __builtin_bit_cast(Wd, b);
+#pragma unroll
+  for (int i = 0; i < W; ++i) {
+    if constexpr (ROWS) {
+      const auto r = __builtin_amdgcn_permlane16_swap(x.w[i], y.w[i], false, false);
+      x.w[i] = r[0];
+      y.w[i] = r[1];
+    }
+    else {
+      const auto r = __builtin_amdgcn_permlane32_swap(x.w[i], y.w[i], false, false);
+      x.w[i] = r[0];
+      y.w[i] = r[1];
+    }
+  }
+  a = __builtin_bit_cast(R, x);
+  b = __builtin_bit_cast(R, y);
+}
+// the sum of a and b with a's total over the pair of halves (rows) in the lower (even) one, b's in the upper (odd) one
+template <bool ROWS, class T>
+__device__ __forceinline__ T swap_add(T a, T b) {
+  if constexpr (TypeInfo<T>::is_complex) {
+    swap_real<ROWS>(a.re, b.re);
+    swap_real<ROWS>(a.im, b.im);
+  }
+  else
+    swap_real<ROWS>(a, b);
+  return c_add(a, b);
+}
+// Sums of 16 values per lane over the 64 lanes of a wave: at every stage a lane keeps half of its values and sends the
+// other half to its partner (upper / lower half, odd / even row, lane ^ 8, the mirror lane of its group of 8), then two
+// plain stages inside the quad.  On return lane l holds the total of value index
+// ((l >> 5) & 1) * 8 + ((l >> 4) & 1) * 4 + ((l >> 3) & 1) * 2 + ((l >> 2) & 1).
 template <class T>
-__device__ __forceinline__ T wave_reduce16(const T (&v)[16], int lane) {
-  T a[8], b4[4], c2[2];
-  const bool h5 = (lane & 32) != 0, h4 = (lane & 16) != 0, h3 = (lane & 8) != 0, h2 = (lane & 4) != 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const T mine = h5 ? v[8 + i] : v[i];
-    const T theirs = h5 ? v[i] : v[8 + i];
-    a[i] = c_add(mine, shfl_xor_t(theirs, 32));
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const T mine = h4 ? a[4 + i] : a[i];
-    const T theirs = h4 ? a[i] : a[4 + i];
-    b4[i] = c_add(mine, shfl_xor_t(theirs, 16));
-  }
+__device__ __forceinline__ T wave_reduce4_tail(const T (&b4)[4], int lane) {
+  T c2[2];
+  const bool h3 = (lane & 8) != 0, h2 = (lane & 4) != 0;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const T mine = h3 ? b4[2 + i] : b4[i];
     const T theirs = h3 ? b4[i] : b4[2 + i];
-    c2[i] = c_add(mine, shfl_xor_t(theirs, 8));
+    c2[i] = c_add(mine, dpp_t<kDppRor8>(theirs));
   }
-  T r = c_add(h2 ? c2[1] : c2[0], shfl_xor_t(h2 ? c2[0] : c2[1], 4));
-  r = c_add(r, shfl_xor_t(r, 2));
-  r = c_add(r, shfl_xor_t(r, 1));
+  T r = c_add(h2 ? c2[1] : c2[0], dpp_t<kDppHalfMirror>(h2 ? c2[0] : c2[1]));
+  r = c_add(r, dpp_t<kDppXor2>(r));
+  r = c_add(r, dpp_t<kDppXor1>(r));
   return r;
 }
-// the same for 8 values (10 exchanges): lane l ends with the total of index ((l >> 5) & 1) * 4 + ((l >> 4) & 1) * 2 + ((l >> 3) & 1)
+template <class T>
+__device__ __forceinline__ T wave_reduce16(const T (&v)[16], int lane) {
+  T a[8], b4[4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    a[i] = swap_add<false>(v[i], v[8 + i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    b4[i] = swap_add<true>(a[i], a[4 + i]);
+  return wave_reduce4_tail(b4, lane);
+}
+// the same for 8 values: lane l ends with the total of index ((l >> 5) & 1) * 4 + ((l >> 4) & 1) * 2 + ((l >> 3) & 1)
 template <class T>
 __device__ __forceinline__ T wave_reduce8(const T (&v)[8], int lane) {
   T b4[4], c2[2];
-  const bool h5 = (lane & 32) != 0, h4 = (lane & 16) != 0, h3 = (lane & 8) != 0;
+  const bool h3 = (lane & 8) != 0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const T mine = h5 ? v[4 + i] : v[i];
-    const T theirs = h5 ? v[i] : v[4 + i];
-    b4[i] = c_add(mine, shfl_xor_t(theirs, 32));
-  }
+  for (int i = 0; i < 4; ++i)
+    b4[i] = swap_add<false>(v[i], v[4 + i]);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const T mine = h4 ? b4[2 + i] : b4[i];
-    const T theirs = h4 ? b4[i] : b4[2 + i];
-    c2[i] = c_add(mine, shfl_xor_t(theirs, 16));
-  }
-  T r = c_add(h3 ? c2[1] : c2[0], shfl_xor_t(h3 ? c2[0] : c2[1], 8));
-  r = c_add(r, shfl_xor_t(r, 4));
-  r = c_add(r, shfl_xor_t(r, 2));
-  r = c_add(r, shfl_xor_t(r, 1));
+  for (int i = 0; i < 2; ++i)
+    c2[i] = swap_add<true>(b4[i], b4[2 + i]);
+  T r = c_add(h3 ? c2[1] : c2[0], dpp_t<kDppRor8>(h3 ? c2[0] : c2[1]));
+  r = c_add(r, dpp_t<kDppHalfMirror>(r));
+  r = c_add(r, dpp_t<kDppXor2>(r));
+  r = c_add(r, dpp_t<kDppXor1>(r));
   return r;
+}
+// the total of one value over the wave, in every lane
+template <class T>
+__device__ __forceinline__ T wave_sum_fast(T v) {
+  v = c_add(v, dpp_t<kDppXor1>(v));
+  v = c_add(v, dpp_t<kDppXor2>(v));
+  v = c_add(v, dpp_t<kDppHalfMirror>(v));
+  v = c_add(v, dpp_t<kDppRor8>(v));
+  v = swap_add<true>(v, v);
+  v = swap_add<false>(v, v);
+  return v;
 }
 __device__ __forceinline__ int wave_reduce8_index(int lane) {
   return ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
@@ -853,7 +908,7 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
           wr[q] = w;
           dotp = c_add(dotp, c_cmul(w, vr[q]));  // (vr is zero beyond the diagonal block)
         }
-        const T dot = wave_sum_t(dotp);
+        const T dot = wave_sum_fast(dotp);
         const T alpha = c_scale(c_mul(dot, tau), R(-0.5));
         T* wd = Lwd + (size_t) wv * kB2tExt;
 #pragma unroll
@@ -907,7 +962,7 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
           if (r > nh)
             ss += c_abs2(v2r[q]);  // (zero outside the rows of B)
         }
-        ss = wave_sum_t(ss);
+        ss = wave_sum_fast(ss);
         const T alpha0 = Lv2[nh];  // (m == 0: row nh holds zero)
         beta = alpha0;
         const R ar = re_of(alpha0), ai = im_of(alpha0);
