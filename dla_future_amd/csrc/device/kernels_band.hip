@@ -23,6 +23,7 @@
 #include "band_api.hpp"
 #include "device_api.hpp"
 #include "gemm_general.hpp"
+#include "lane_ops.hpp"
 
 namespace dlaf_mi355x {
 
@@ -479,18 +480,7 @@ constexpr int kTfMax = 1024;  // 4 rows of 1024 complex doubles = 64 KiB of LDS
 
 template <class T>
 __device__ __forceinline__ T wave_sum(T v) {
-  using R = real_t<T>;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    if constexpr (TypeInfo<T>::is_complex) {
-      v.re += __shfl_xor(v.re, off);
-      v.im += __shfl_xor(v.im, off);
-    }
-    else
-      v += __shfl_xor(v, off);
-  }
-  (void) sizeof(R);
-  return v;
+  return wave_sum_fast(v);  // (lane_ops.hpp: DPP + permlane swaps -- the T-factor kernel does one per step of its chain)
 }
 
 // kTfU: registers per lane and column (columns of up to 64 * kTfU rows), kTfD: columns in flight
