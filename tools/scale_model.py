@@ -126,7 +126,7 @@ def model(n, nb, pr, pc, cx, schedule, fab, reserve=32.0 / 512.0):
 
 def model_c5(pr, pc, fab):
     """BASELINE configs[4]: the Hermitian eigensolver at N = 20480, nb = 512 (band 128), fp64, on a pr x pc grid.  Stage
-    times of one MI355X measured in round 4 (profiles/r04_eigensolver_N20480_nb512_bench.txt: 0.352 + 0.427 + 0.292 + 0.476 + 0.313 s), split into the part every
+    times of one MI355X measured in round 4 (profiles/r04_eigensolver_N20480_nb512_bench.txt: 0.350 + 0.354 + 0.292 + 0.462 + 0.309 s), split into the part every
     rank repeats (replicated) and the part the grid shares; communication from the guide's xGMI figures.  What is
     replicated today: the panel factorization of reduction_to_band inside the owning process column (and the T / W / W2
     products every rank recomputes), band_to_tridiagonal (one persistent bulge-chasing launch per rank),
@@ -140,12 +140,12 @@ def model_c5(pr, pc, fab):
     # per panel: the factored panel along the process row, the all-reduce of X over the grid (m x b doubles each, m ~ n / 2)
     msg = (n / 2) * b * 8
     t1_comm = npanels * (fab.bcast(msg, pc) + (2 * fab.bcast(msg, P) if P > 1 else 0.0))
-    t2 = 0.427 + (2 * fab.bcast(2 * b * n * 8, P) if P > 1 else 0.0)
+    t2 = 0.354 + (2 * fab.bcast(2 * b * n * 8, P) if P > 1 else 0.0)
     # stage 3: Q U of the large merges shared (0.17 s of GEMMs), the rest replicated; all-gather of n x n doubles at the top
     # level, half of that at each level below (seven links per GPU)
     t3 = 0.12 + 0.17 / P + ((2.0 * n * n * 8 * (P - 1) / P) / (7 * fab.bw) + 4 * fab.lat if P > 1 else 0.0)
-    t4 = 0.476 / pc
-    t5 = 0.313 / P + (npanels / 4) * fab.bcast((n / 2) * 512 * 8, pc) * (1 if P > 1 else 0)
+    t4 = 0.462 / pc
+    t5 = 0.309 / P + (npanels / 4) * fab.bcast((n / 2) * 512 * 8, pc) * (1 if P > 1 else 0)
     t1 = t1_rep + t1_sh / P + t1_comm
     return t1, t2, t3, t4, t5
 
