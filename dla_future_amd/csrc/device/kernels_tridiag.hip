@@ -470,8 +470,12 @@ __global__ __launch_bounds__(kB2tThreads) void b2t_kernel(B2tArgs<T> p) {
 // reflector) that a thread ever needs are four registers each, loaded once per phase, and z = A v accumulates in four
 // registers per thread; per column there is one broadcast operand and one wave reduction.
 // Loads are sc1 buffer loads, which the compiler pipelines like plain loads (relaxed atomic loads, the other sc1 form,
-// it issues one at a time); an element outside the block is set to zero after its load and stored to an out-of-range
-// offset (dropped by the descriptor's bounds check), so a step is the same straight-line code for every element.
+// it issues one at a time); an element outside the block is loaded from and stored to an out-of-range offset (zero /
+// dropped by the descriptor's bounds check, no traffic), so a step is the same straight-line code for every element.
+// Round 4 (profiles/r04_b2t_phases.txt): the first column of a step's block is stored and
+// published as soon as it is final -- it is all the successor's step waits for --, the progress word is polled by wave 0
+// with scalar loads and relayed through LDS, P5 has an instance for full blocks, the wave reductions run on permlane
+// swaps and DPP (lane_ops.hpp).
 constexpr int kB2tRegBand = 128;
 constexpr int kB2tExt = 2 * kB2tRegBand;  // rows of a block
 
