@@ -1019,6 +1019,12 @@ __global__ __launch_bounds__(NT) void b2t_reg_kernel(B2tArgs<T> p) {
         atomicCAS(p.info, 0, kInfoSchedulingFailure);
       }
     }
+    // A sweep is done only once its predecessor is.  "Done" answers every wait of the successor, also those for steps
+    // this sweep never had -- and this sweep's last step waited for the FIRST COLUMN of the predecessor's next step only:
+    // without this wait the predecessor could still be storing the rest of that step (its second column is the last
+    // column of a block of sweep s + 1) when sweep s + 1 is let through.  Found by enumeration of the protocol on the CPU
+    // (tests/test_b2t_handoff_model.py); a short wait at the end of a sweep, off every critical path.
+    wave_wait(kB2tDone);
     publish(kB2tDone);
     __syncthreads();
   }
