@@ -39,7 +39,9 @@ def build(n, b, weaken=None):
         col = range(s, s + 1)
         acc.append((last, "r", elems(range(s + 1, s + 1 + b), col)))
         acc.append((last, "w", elems(range(s + 1, s + 1 + b), col)))
-        if s > 0 and nsteps(n, b, s - 1) > 0 and weaken != "prologue":
+        if s > 0 and nsteps(n, b, s - 1) > 0 and weaken == "generic_kernel":
+            prog.append((E(("ST", s - 1, 0)), last))   # (the predecessor has finished one step)
+        elif s > 0 and nsteps(n, b, s - 1) > 0 and weaken != "prologue":
             prog.append((E(("FC", s - 1, 0)), last))
         for t in range(nsteps(n, b, s)):
             j = 1 + s + t * b
@@ -52,7 +54,12 @@ def build(n, b, weaken=None):
             acc.append((ll, "r", elems(rows, range(j + b - 1, j + b))))
             acc.append((fc, "w", elems(rows, range(j, j + 1))))
             acc.append((st, "w", elems(rows, range(j + 1, j + b))))
-            if s > 0:
+            if s > 0 and weaken == "generic_kernel":
+                # b2t_kernel (complex double, bands above 128) and the reference's semaphores (mc.h:683-709): a step runs once
+                # the predecessor has finished t + 2 steps, or all it has; no early column, no chain of "done"
+                ps = nsteps(n, b, s - 1)
+                prog.append((E(("ST", s - 1, min(t + 1, ps - 1))), le))
+            elif s > 0:
                 ps = nsteps(n, b, s - 1)
                 # (1) the predecessor has finished its step t (or is done)
                 prog.append((E(("ST", s - 1, t)) if t < ps else E(("DONE", s - 1)), le))
@@ -61,7 +68,7 @@ def build(n, b, weaken=None):
                     prog.append((E(("FC", s - 1, t + 1)) if t + 1 < ps else E(("DONE", s - 1)), ll))
         done = E(("DONE", s))
         prog.append((last, done))
-        if s > 0 and weaken != "done_chain":
+        if s > 0 and weaken not in ("done_chain", "generic_kernel"):
             prog.append((E(("DONE", s - 1)), done))   # a sweep is done only once its predecessor is
     return ev, prog, acc
 
@@ -111,3 +118,10 @@ def test_the_model_notices_a_wait_that_is_too_weak():
     assert unordered_conflicts(23, 3, weaken="last_column")[0]
     assert unordered_conflicts(23, 3, weaken="prologue")[0]
     assert unordered_conflicts(23, 3, weaken="done_chain")[0]   # (what the kernel did before the model was written)
+
+
+@pytest.mark.parametrize("n,b", [(23, 3), (41, 5), (37, 8)])
+def test_the_generic_kernels_protocol_orders_every_pair_too(n, b):
+    """step t after the predecessor has finished t + 2 steps (or all of them): the protocol of b2t_kernel and of the reference"""
+    bad, names = unordered_conflicts(n, b, weaken="generic_kernel")
+    assert not bad, [(el, names[u], names[v]) for el, u, v in bad[:5]]
